@@ -1,0 +1,191 @@
+/*
+ * remap_amd.h — C ABI of the MI355X-native alignment hot path of kataklinger/remap.
+ *
+ * The reference has no FFI: its boundary is the C++ template surface that main.cpp and
+ * mpb.hpp compile against.  The replacement headers under include/remap/
+ * keep those names and forward their heavy methods to the entry points declared here.
+ * Every entry point cites the reference interface it replaces (file:line under
+ * /root/reference/src).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns RMX_OK (0) or a negative rmx_status; nothing throws;
+ *   - all frame / table / canvas pointers are DEVICE pointers (HBM) unless the parameter
+ *     is documented as host; the library never allocates or frees caller buffers;
+ *   - work is enqueued on the context's HIP stream; rmx_sync() waits for it.  Functions
+ *     that return host-visible scalars (counts, status words) synchronise internally
+ *     and say so;
+ *   - a context is thread-compatible (one thread at a time), contexts are independent.
+ */
+#ifndef REMAP_AMD_H
+#define REMAP_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rmx_status {
+  RMX_OK = 0,
+  RMX_ERR_ARG = -1,      /* null pointer, zero size, unsupported dimensions            */
+  RMX_ERR_DEVICE = -2,   /* a HIP call failed; rmx_last_error() has the HIP string     */
+  RMX_ERR_KMAX = -3,     /* a frame produced more keypoints than the table stride      */
+  RMX_ERR_CAPACITY = -4, /* an internal workspace limit (pairs / offsets) was exceeded */
+  RMX_ERR_NOGPU = -5     /* no HIP device visible                                      */
+} rmx_status;
+
+/* One keypoint = one row of a frame's descriptor table.
+ * code        : kpr::code, kpr.hpp:20-23 — 25 native nibbles of the 5x5 patch, row-major,
+ *               pixel i in nibble i (even nibble = low half), nibble 25 = weight
+ *               (kpe.hpp:342-379).
+ * region_mask : bit (grid_h*col + row) set for every kpr::grid region the point was added
+ *               to (kpe.hpp:157-192,235-277; kpr.hpp:189-219).
+ * x, y        : absolute image coordinates (mrl::point_t in kpe.hpp:228,303).
+ * Rows of one frame are ordered x ascending, then y ascending — the order in which
+ * kpe::extractor emits them (kpe.hpp:201-205,289). */
+typedef struct rmx_desc {
+  uint8_t code[13];
+  uint8_t region_mask;
+  uint16_t x;
+  uint16_t y;
+} rmx_desc; /* 18 bytes, alignment 2 */
+
+/* kpm::vote, kpm.hpp:37-65 (count_ narrowed to 32 bits). */
+typedef struct rmx_vote {
+  int32_t dx;
+  int32_t dy;
+  uint32_t count;
+  uint32_t valid; /* 0 = std::nullopt */
+} rmx_vote;
+
+typedef struct rmx_ctx rmx_ctx;
+
+/* ---- context ------------------------------------------------------------------------ */
+
+/* Replaces the construction of kpe::extractor<Grid,Overlap>{dims} (kpe.hpp:84-90) and of
+ * frc::collector{dims} (frc.hpp:51-53): fixes frame width/height, the region grid
+ * (4x2 overlap 16 for frc.hpp:22-26, 1x1 overlap 0 for fgs.hpp:17,85) and the stride
+ * (kmax rows) of per-frame descriptor tables.  `stream` is a hipStream_t passed as
+ * void* (NULL = the device's default stream). */
+int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
+                   uint32_t grid_h, uint32_t overlap, uint32_t kmax, void* stream,
+                   rmx_ctx** out);
+int rmx_ctx_destroy(rmx_ctx* ctx);
+int rmx_sync(rmx_ctx* ctx);
+const char* rmx_last_error(const rmx_ctx* ctx);
+/* Number of bytes of device workspace the context currently holds (diagnostics). */
+size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx);
+
+/* ---- kpe: keypoint extraction --------------------------------------------------------- */
+
+/* Batched kpe::extractor::extract (kpe.hpp:92-108) over n frames stored back to back
+ * (row-major u8, one 4-bit palette index per byte).
+ *   median : n*W*H bytes; processed pixels get ordered_to_native(4th largest of the 3x3
+ *            window) (kpe.hpp:308-340), the unprocessed border is written 0 (the
+ *            reference's freshly allocated image, frc.hpp:106).
+ *   desc   : n*kmax rows; frame f's table starts at desc + f*kmax and holds kcount[f]
+ *            rows in reference scan order.
+ *   kcount : n uint32.
+ * Asynchronous.  A frame with more than kmax keypoints keeps its first kmax rows in
+ * scan order and sets the overflow flag reported by rmx_kpe_status(). */
+int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* median,
+                  rmx_desc* desc, uint32_t* kcount);
+/* Synchronises; returns RMX_ERR_KMAX if any frame since the last call overflowed kmax and
+ * stores the largest per-frame keypoint count seen in *max_k (may be NULL). */
+int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k);
+
+/* ---- kpm: keypoint matching ---------------------------------------------------------- */
+
+/* Batched grid-variant kpm::match(cfg, previous, current) (kpm.hpp:395-415) with
+ * frc::collector::match_config (frc.hpp:30-44: weight_switch 10, region_votes 3) for the
+ * n-1 consecutive pairs (f-1, f), f = 1..n-1, of a table batch produced by rmx_kpe_batch.
+ *   halo_desc/halo_kcount : optional table of the frame preceding frames[0] (the last
+ *            frame of the previous batch or of the previous rank's shard); when non-NULL
+ *            pair (halo, 0) is matched too, otherwise frame 0 reports matched = 0.
+ *   dxdy    : n*2 int32, (dx,dy) = previous - current (kpm.hpp:96-98); (0,0) if unmatched
+ *   matched : n uint8, 1 = std::optional engaged.
+ * Tie-breaking reproduces libstdc++'s std::unordered_map iteration order exactly
+ * (kpm.hpp:134-138) — on the device, there is no host replay. */
+int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint32_t n,
+                const rmx_desc* halo_desc, const uint32_t* halo_kcount, int32_t* dxdy,
+                uint8_t* matched);
+
+/* frc::collector::process_frame's state update (frc.hpp:109-115,124-127) as a segmented
+ * prefix sum: a matched frame accumulates its offset onto the running position, an
+ * unmatched frame opens a new fragment at (0,0).
+ *   first_is_start : 1 if frame 0 is the first frame of the stream (frc.hpp:83-95), else
+ *                    the running state (*carry_pos, *carry_frag) of the previous batch is
+ *                    continued (host pointers, updated on return).
+ *   pos      : n*2 int32 frame position inside its fragment
+ *   frag_id  : n uint32 fragment index (0-based, monotone)
+ * Synchronises (returns the carry to the host). */
+int rmx_frc_scan(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint32_t n,
+                 int first_is_start, int32_t carry_pos[2], uint32_t* carry_frag,
+                 int32_t* pos, uint32_t* frag_id);
+
+/* ---- fgm: fragment canvas ------------------------------------------------------------- */
+
+/* fgm::fragment::blit(pos, image, packed, no) (fgm.hpp:87-97,176-188) for a batch of
+ * frames into ONE canvas of `dot` histograms (fgm::dot_type = uint16[16], fgm.hpp:12-14):
+ * ++canvas[y + pos.y - zero.y][x + pos.x - zero.x][frame[y][x]], uint16 wraparound.
+ * Only frames whose frag_id[f] == fragment are blitted (frag_id may be NULL = all).  The
+ * canvas must already cover every blit (size it with rmx_fgm_extent). */
+int rmx_fgm_blit_batch(rmx_ctx* ctx, const uint8_t* frames, const int32_t* pos,
+                       const uint32_t* frag_id, uint32_t fragment, uint32_t n,
+                       uint16_t* canvas, uint32_t canvas_w, uint32_t canvas_h,
+                       int32_t zero_x, int32_t zero_y);
+
+/* fgm::fragment::ensure/extend/get_step (fgm.hpp:190-233) in closed form: the final
+ * canvas of a fragment whose first blit is at (0,0) is the minimal box, grown from the
+ * initial step-sized canvas in whole multiples of `step` (= frame dims) on each side, that
+ * covers all blits; it does not depend on blit order.  Host-side, pure function.
+ *   pos : n*2 int32 HOST positions of the fragment's frames. */
+int rmx_fgm_extent(const int32_t* pos, uint32_t n, uint32_t step_w, uint32_t step_h,
+                   uint32_t* canvas_w, uint32_t* canvas_h, int32_t* zero_x,
+                   int32_t* zero_y);
+
+/* fgm::fragment::blit(pos, fragment&&) canvas part (fgm.hpp:99-113): dst[y+oy][x+ox][b] +=
+ * src[y][x][b] for every bin, uint16 wraparound; (ox,oy) = pos - dst.zero, already
+ * inside dst. */
+int rmx_fgm_merge(rmx_ctx* ctx, uint16_t* dst, uint32_t dst_w, uint32_t dst_h,
+                  const uint16_t* src, uint32_t src_w, uint32_t src_h, int32_t ox,
+                  int32_t oy);
+
+/* fgm::fragment::blend (fgm.hpp:115-135): image = first arg-max bin, mask = 1 where any
+ * bin is non-zero (image 0 / mask 0 elsewhere). */
+int rmx_fgm_blend(rmx_ctx* ctx, const uint16_t* canvas, uint32_t canvas_w,
+                  uint32_t canvas_h, uint8_t* image, uint8_t* mask);
+
+/* ---- fgs: fragment splicing ------------------------------------------------------------ */
+
+/* Cellular-variant kpm::match(preg, pmask, creg, cmask, cell) (kpm.hpp:371-393) for a list
+ * of fragment pairs (fgs::match_partial / match_all, fgs.hpp:119-140).  Fragment i is
+ * described by its single-region descriptor table (grid 1x1, overlap 0), its blend mask
+ * and its canvas dimensions.
+ *   tables/kcounts/masks : HOST arrays of nfrag DEVICE pointers / counts
+ *   dims   : nfrag*2 uint32 HOST (width, height)
+ *   pairs  : npairs*2 uint32 HOST (previous index, current index)
+ *   votes  : npairs rmx_vote HOST out
+ * Synchronises. */
+int rmx_kpm_cell_pairs(rmx_ctx* ctx, const rmx_desc* const* tables,
+                       const uint32_t* kcounts, const uint8_t* const* masks,
+                       const uint32_t* dims, uint32_t nfrag, const uint32_t* pairs,
+                       uint32_t npairs, uint32_t cell_w, uint32_t cell_h, rmx_vote* votes);
+
+/* ---- introspection ----------------------------------------------------------------------- */
+
+/* Library version / build string, e.g. "remap_amd 0.1 gfx950". */
+const char* rmx_version(void);
+/* The two 16-entry luminance-rank LUTs (cpl.hpp:163-217) the kernels use. */
+void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
+/* Average duration in milliseconds of the last rmx_kpe_batch's main kernel, measured with
+ * HIP events on the context stream (0 if timing was not enabled). */
+int rmx_set_timing(rmx_ctx* ctx, int enabled);
+int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* REMAP_AMD_H */
