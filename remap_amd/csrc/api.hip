@@ -1,0 +1,268 @@
+// api.hip — C ABI of remap_amd (include/remap_amd.h): context, workspace, kernel launches.
+// One translation unit: the kernel files are included so a single hipcc invocation builds
+// libremap_amd.so for gfx950.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kpe.hip"
+#include "table.hip"
+#include "kpm.hip"
+#include "fgm.hip"
+
+using namespace rmx;
+
+struct rmx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  uint32_t W = 0, H = 0, gw = 0, gh = 0, overlap = 0, kmax = 0;
+  Bands bands{};
+  // workspace (device)
+  RawDesc* raw = nullptr;
+  uint32_t* kraw = nullptr;
+  uint32_t n_cap = 0;
+  uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
+  KpmWorkspace kpm{};
+  size_t ws_bytes = 0;
+  // timing
+  bool timing = false;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  float ms_kpe = 0.f, ms_table = 0.f, ms_kpm_build = 0.f, ms_kpm_match = 0.f, ms_blit = 0.f;
+  std::string err;
+};
+
+namespace {
+
+#define RMX_HIP(call)                                                                    \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                      \
+      return RMX_ERR_DEVICE;                                                             \
+    }                                                                                    \
+  } while (0)
+
+Bands make_bands(uint32_t W, uint32_t H, uint32_t gw, uint32_t gh, uint32_t ov) {
+  Bands b{};
+  b.gw = gw;
+  b.gh = gh;
+  uint32_t rw = W / gw - ov / 2, rh = H / gh - ov / 2;
+  for (uint32_t c = 0; c < gw; ++c) {
+    uint32_t s = 2 + c * (rw + ov);
+    b.x0[c] = (uint16_t)(c ? s - ov : s);
+    b.x1[c] = (uint16_t)((c + 1 < gw) ? s + rw + ov : W - 2);
+  }
+  for (uint32_t r = 0; r < gh; ++r) {
+    uint32_t t = 3 + r * (rh + ov);
+    b.y0[r] = (uint16_t)(r ? t - ov : 2);
+    b.y1[r] = (uint16_t)((r + 1 < gh) ? t + rh + ov : H - 4);
+  }
+  return b;
+}
+
+int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
+  if (n <= ctx->n_cap) return RMX_OK;
+  if (ctx->raw) (void)hipFree(ctx->raw);
+  if (ctx->kraw) (void)hipFree(ctx->kraw);
+  ctx->raw = nullptr;
+  ctx->kraw = nullptr;
+  ctx->n_cap = 0;
+  RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
+  RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
+  ctx->n_cap = n;
+  ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + kpm_workspace_bytes(ctx->kpm);
+  return RMX_OK;
+}
+
+struct Timer {
+  rmx_ctx* c;
+  float* out;
+  Timer(rmx_ctx* c_, float* o) : c(c_), out(o) {
+    if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+  }
+  ~Timer() {
+    if (c->timing) {
+      (void)hipEventRecord(c->ev1, c->stream);
+      (void)hipEventSynchronize(c->ev1);
+      (void)hipEventElapsedTime(out, c->ev0, c->ev1);
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+const char* rmx_version(void) { return "remap_amd 0.1 gfx950"; }
+
+void rmx_luts(uint8_t n2o[16], uint8_t o2n[16]) {
+  std::memcpy(n2o, kN2O, 16);
+  std::memcpy(o2n, kO2N, 16);
+}
+
+int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w, uint32_t grid_h,
+                   uint32_t overlap, uint32_t kmax, void* stream, rmx_ctx** out) {
+  if (!out) return RMX_ERR_ARG;
+  *out = nullptr;
+  // W % 4: a lane owns one aligned dword of a row.  Lower bounds: the band arithmetic of
+  // kpe.hpp:84-90 needs every region to start inside the frame.  x,y are uint16 in rmx_desc.
+  if (width % 4 || width < 16 || height < 8 || width > 65532 || height > 65535) return RMX_ERR_ARG;
+  if (grid_w < 1 || grid_h < 1 || grid_w > 4 || grid_h > 4 || grid_w * grid_h > 8) return RMX_ERR_ARG;
+  if (kmax < 1 || kmax > 16384) return RMX_ERR_ARG;
+  {
+    uint32_t rw = width / grid_w, rh = height / grid_h;
+    if (rw <= overlap / 2 || rh <= overlap / 2) return RMX_ERR_ARG;
+    rw -= overlap / 2;
+    rh -= overlap / 2;
+    if (2 + (grid_w - 1) * (rw + overlap) > width - 2 || 3 + (grid_h - 1) * (rh + overlap) > height - 4)
+      return RMX_ERR_ARG;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return RMX_ERR_NOGPU;
+  if (device < 0 || device >= ndev) return RMX_ERR_ARG;
+  rmx_ctx* ctx = new (std::nothrow) rmx_ctx();
+  if (!ctx) return RMX_ERR_DEVICE;
+  ctx->device = device;
+  ctx->stream = (hipStream_t)stream;
+  ctx->W = width;
+  ctx->H = height;
+  ctx->gw = grid_w;
+  ctx->gh = grid_h;
+  ctx->overlap = overlap;
+  ctx->kmax = kmax;
+  ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
+  if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+    delete ctx;
+    return RMX_ERR_DEVICE;
+  }
+  *out = ctx;
+  return RMX_OK;
+}
+
+int rmx_ctx_destroy(rmx_ctx* ctx) {
+  if (!ctx) return RMX_ERR_ARG;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->raw) (void)hipFree(ctx->raw);
+  if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->status) (void)hipFree(ctx->status);
+  kpm_workspace_free(ctx->kpm);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  delete ctx;
+  return RMX_OK;
+}
+
+int rmx_sync(rmx_ctx* ctx) {
+  if (!ctx) return RMX_ERR_ARG;
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  return RMX_OK;
+}
+
+const char* rmx_last_error(const rmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+int rmx_set_timing(rmx_ctx* ctx, int enabled) {
+  if (!ctx) return RMX_ERR_ARG;
+  ctx->timing = enabled != 0;
+  return RMX_OK;
+}
+
+int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) {
+  if (!ctx || !kernel || !ms) return RMX_ERR_ARG;
+  std::string k(kernel);
+  if (k == "kpe_main")
+    *ms = ctx->ms_kpe;
+  else if (k == "kpe_table")
+    *ms = ctx->ms_table;
+  else if (k == "kpm_build")
+    *ms = ctx->ms_kpm_build;
+  else if (k == "kpm_match")
+    *ms = ctx->ms_kpm_match;
+  else if (k == "fgm_blit")
+    *ms = ctx->ms_blit;
+  else
+    return RMX_ERR_ARG;
+  return RMX_OK;
+}
+
+int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* median, rmx_desc* desc,
+                  uint32_t* kcount) {
+  if (!ctx || !frames || !median || !desc || !kcount || n == 0 || n > 0x0fffffffu) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  if (int rc = ensure_workspace(ctx, n)) return rc;
+  RMX_HIP(hipMemsetAsync(ctx->kraw, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
+  KpeParams p{};
+  p.frames = frames;
+  p.median = median;
+  p.raw = ctx->raw;
+  p.kcount = ctx->kraw;
+  p.status = ctx->status;
+  p.n = n;
+  p.W = ctx->W;
+  p.H = ctx->H;
+  p.Wd = ctx->W / 4;
+  p.V = (uint64_t)n * p.Wd;
+  p.groups = (uint32_t)((p.V + 61) / 62);
+  // strips: enough waves to fill the chip for small batches, long strips for big ones
+  uint32_t rps = 60;
+  while (rps > 12 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 12;
+  p.rows_per_strip = rps;
+  p.kmax = ctx->kmax;
+  dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
+  {
+    Timer t(ctx, &ctx->ms_kpe);
+    hipLaunchKernelGGL(kpe_main, grid, dim3(256), 0, ctx->stream, p);
+  }
+  RMX_HIP(hipGetLastError());
+  TableParams tp{};
+  tp.raw = ctx->raw;
+  tp.kcount = ctx->kraw;
+  tp.desc = desc;
+  tp.kout = kcount;
+  tp.status = ctx->status;
+  tp.n = n;
+  tp.kmax = ctx->kmax;
+  tp.bands = ctx->bands;
+  uint32_t n2 = 1;
+  while (n2 < ctx->kmax) n2 <<= 1;
+  {
+    Timer t(ctx, &ctx->ms_table);
+    hipLaunchKernelGGL(kpe_table, dim3(n), dim3(256), n2 * sizeof(uint64_t), ctx->stream, tp);
+  }
+  RMX_HIP(hipGetLastError());
+  return RMX_OK;
+}
+
+int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k) {
+  if (!ctx) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  uint32_t st[2] = {0, 0};
+  RMX_HIP(hipMemcpyAsync(st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  if (max_k) {
+    *max_k = 0;
+    if (ctx->n_cap) {
+      std::vector<uint32_t> k(ctx->n_cap);
+      RMX_HIP(hipMemcpy(k.data(), ctx->kraw, (size_t)ctx->n_cap * 4, hipMemcpyDeviceToHost));
+      for (uint32_t v : k) *max_k = std::max(*max_k, v);
+    }
+  }
+  if (st[0]) {
+    RMX_HIP(hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
+    return RMX_ERR_KMAX;
+  }
+  return RMX_OK;
+}
+
+}  // extern "C"
+
+#include "api_kpm_fgm.inc"

@@ -1,0 +1,97 @@
+// common.h — shared device/host definitions for the gfx950 kernels of remap_amd.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/remap_amd.h"
+
+namespace rmx {
+
+// ---- luminance-rank LUTs (reference: cpl.hpp:163-217; values verified in SURVEY.md §8a-1) ----
+// native_to_ordered = {0,15,2,12,6,9,3,13,5,1,7,4,8,14,10,11}
+// ordered_to_native = {0,9,2,6,11,8,4,10,12,5,14,15,3,7,13,1}
+// Derived on the host at library load from the palette (api.hip: init_luts) and checked
+// against these constants; the kernels use byte tables packed for v_perm_b32:
+//   kKey[v] = native_to_ordered[v] << 4 | v   ("key": orders like the rank, carries the
+//             native value in its low nibble, so rank selection needs no inverse LUT)
+//   kOrd[v] = native_to_ordered[v]
+#define RMX_N2O                                                  \
+  { 0, 15, 2, 12, 6, 9, 3, 13, 5, 1, 7, 4, 8, 14, 10, 11 }
+#define RMX_O2N                                                  \
+  { 0, 9, 2, 6, 11, 8, 4, 10, 12, 5, 14, 15, 3, 7, 13, 1 }
+
+constexpr uint8_t kN2O[16] = RMX_N2O;
+constexpr uint8_t kO2N[16] = RMX_O2N;
+
+constexpr uint32_t key_of(int v) { return (uint32_t)(kN2O[v] << 4 | v); }
+constexpr uint32_t ord_of(int v) { return (uint32_t)kN2O[v]; }
+constexpr uint32_t key4(int b) { return key_of(b) | key_of(b + 1) << 8 | key_of(b + 2) << 16 | key_of(b + 3) << 24; }
+constexpr uint32_t ord4(int b) { return ord_of(b) | ord_of(b + 1) << 8 | ord_of(b + 2) << 16 | ord_of(b + 3) << 24; }
+
+// v_perm_b32: D.byte[i] = {S0:S1}.byte[sel.byte[i]], selector 0-3 -> S1, 4-7 -> S0.
+__device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel) {
+  return __builtin_amdgcn_perm(s0, s1, sel);
+}
+
+// Map four packed pixels (one 0..15 value per byte) through a 16-entry byte table given as
+// four dwords (entries 0-3, 4-7, 8-11, 12-15): 8 VALU ops per 4 pixels.
+template <uint32_t T0, uint32_t T1, uint32_t T2, uint32_t T3>
+__device__ __forceinline__ uint32_t map16(uint32_t w) {
+  uint32_t sel = w & 0x07070707u;
+  uint32_t a = perm(T1, T0, sel);
+  uint32_t b = perm(T3, T2, sel);
+  uint32_t m1 = (w >> 3) & 0x01010101u;
+  uint32_t m = (m1 << 8) - m1;  // 0xff in every byte whose value is >= 8
+  return (b & m) | (a & ~m);
+}
+__device__ __forceinline__ uint32_t map_key(uint32_t w) { return map16<key4(0), key4(4), key4(8), key4(12)>(w); }
+__device__ __forceinline__ uint32_t map_ord(uint32_t w) { return map16<ord4(0), ord4(4), ord4(8), ord4(12)>(w); }
+
+// 3-input integer min/max/median, one VALU op each.  Written as asm because hipcc CSEs the
+// min/max pairs of a sort3 into six 2-input ops instead of v_min3/v_med3/v_max3.
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_min3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_max3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+__device__ __forceinline__ uint32_t umed3(uint32_t a, uint32_t b, uint32_t c) {
+  uint32_t d;
+  asm("v_med3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c));
+  return d;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t mbcnt(uint64_t mask) {
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Raw keypoint record emitted by the kpe kernel (unordered within a frame).
+struct __attribute__((aligned(16))) RawDesc {
+  uint32_t code[4];  // 13 code bytes, little-endian, byte 12 = weight | p24 << 4; bytes 13-15 zero
+  uint32_t xy;       // x | y << 16
+  uint32_t pad[3];
+};
+static_assert(sizeof(RawDesc) == 32, "RawDesc");
+
+// Region band limits (kpe.hpp:84-90,157-192,235-277 in closed form).
+struct Bands {
+  uint32_t gw, gh;
+  uint16_t x0[4], x1[4], y0[4], y1[4];
+};
+
+__host__ __device__ inline uint32_t region_mask(const Bands& b, uint32_t x, uint32_t y) {
+  uint32_t m = 0;
+  for (uint32_t c = 0; c < b.gw; ++c)
+    if (x >= b.x0[c] && x < b.x1[c])
+      for (uint32_t r = 0; r < b.gh; ++r)
+        if (y >= b.y0[r] && y < b.y1[r]) m |= 1u << (b.gh * c + r);
+  return m;
+}
+
+}  // namespace rmx

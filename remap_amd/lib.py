@@ -1,0 +1,250 @@
+"""ctypes binding of the C ABI (include/remap_amd.h) + build helper.
+
+The shared library is built in-tree (remap_amd/libremap_amd.so) by ``build()`` with one hipcc
+invocation for gfx950.  There is NO CPU fallback: if the library is missing or no GPU is
+visible, every compute entry point raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+SO_PATH = os.path.join(HERE, "libremap_amd.so")
+SRC_DIR = os.path.join(HERE, "csrc")
+
+DESC_DTYPE = np.dtype([("code", np.uint8, (13,)), ("region_mask", np.uint8), ("x", np.uint16), ("y", np.uint16)],
+                      align=False)
+VOTE_DTYPE = np.dtype([("dx", np.int32), ("dy", np.int32), ("count", np.uint32), ("valid", np.uint32)])
+DESC_BYTES = 18
+
+RMX_OK = 0
+STATUS = {0: "RMX_OK", -1: "RMX_ERR_ARG", -2: "RMX_ERR_DEVICE", -3: "RMX_ERR_KMAX", -4: "RMX_ERR_CAPACITY",
+          -5: "RMX_ERR_NOGPU"}
+
+# every symbol include/remap_amd.h declares
+SYMBOLS = [
+    "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
+    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
+    "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
+    "rmx_last_kernel_ms",
+]
+
+
+class RemapError(RuntimeError):
+    def __init__(self, code, where, detail=""):
+        self.code = code
+        super().__init__(f"{where}: {STATUS.get(code, code)} {detail}".strip())
+
+
+def sources():
+    return sorted(os.path.join(SRC_DIR, f) for f in os.listdir(SRC_DIR)
+                  if f.endswith((".hip", ".h", ".inc")))
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = sources() + [os.path.join(ROOT, "include", "remap_amd.h")]
+    return any(os.path.getmtime(s) > t for s in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -> remap_amd/libremap_amd.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
+           os.path.join(SRC_DIR, "api.hip"), "-o", SO_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return SO_PATH
+
+
+_lib = None
+
+
+def load():
+    """Load the library (building it if the sources are newer).  Raises if it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if needs_build():
+        build()
+    lib = C.CDLL(SO_PATH)
+    vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
+    lib.rmx_version.restype = C.c_char_p
+    lib.rmx_last_error.restype = C.c_char_p
+    lib.rmx_last_error.argtypes = [vp]
+    lib.rmx_ctx_workspace_bytes.restype = C.c_size_t
+    lib.rmx_ctx_workspace_bytes.argtypes = [vp]
+    lib.rmx_ctx_create.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, vp, C.POINTER(vp)]
+    lib.rmx_ctx_destroy.argtypes = [vp]
+    lib.rmx_sync.argtypes = [vp]
+    lib.rmx_kpe_batch.argtypes = [vp, vp, u32, vp, vp, vp]
+    lib.rmx_kpe_status.argtypes = [vp, C.POINTER(u32)]
+    lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
+    lib.rmx_fgm_blit_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32, i32, i32]
+    lib.rmx_fgm_extent.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32),
+                                   C.POINTER(i32)]
+    lib.rmx_fgm_merge.argtypes = [vp, vp, u32, u32, vp, u32, u32, i32, i32]
+    lib.rmx_fgm_blend.argtypes = [vp, vp, u32, u32, vp, vp]
+    lib.rmx_kpm_cell_pairs.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, u32, vp]
+    lib.rmx_luts.argtypes = [vp, vp]
+    lib.rmx_set_timing.argtypes = [vp, C.c_int]
+    lib.rmx_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+    _lib = lib
+    return lib
+
+
+def luts():
+    lib = load()
+    a = np.zeros(16, np.uint8)
+    b = np.zeros(16, np.uint8)
+    lib.rmx_luts(a.ctypes.data, b.ctypes.data)
+    return a, b
+
+
+class Context:
+    """rmx_ctx: one per (device, frame size, grid).  Buffers are torch CUDA tensors whose
+    ``data_ptr()`` crosses the C ABI; torch is plumbing for device memory and streams only."""
+
+    def __init__(self, width, height, grid=(4, 2), overlap=16, kmax=2048, device=0, stream=None):
+        import torch
+
+        self.lib = load()
+        self.torch = torch
+        if not torch.cuda.is_available():
+            raise RemapError(-5, "Context", "no HIP device visible (the HIP path has no CPU fallback)")
+        self.device = torch.device("cuda", device)
+        self.W, self.H, self.grid, self.overlap, self.kmax = width, height, grid, overlap, kmax
+        self.nreg = grid[0] * grid[1]
+        if stream is None:
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        self.stream = stream
+        h = C.c_void_p()
+        rc = self.lib.rmx_ctx_create(device, width, height, grid[0], grid[1], overlap, kmax, C.c_void_p(stream),
+                                     C.byref(h))
+        if rc:
+            raise RemapError(rc, "rmx_ctx_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.rmx_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc, where):
+        if rc:
+            raise RemapError(rc, where, self.lib.rmx_last_error(self.h).decode())
+
+    def sync(self):
+        self._chk(self.lib.rmx_sync(self.h), "rmx_sync")
+
+    def set_timing(self, on=True):
+        self.lib.rmx_set_timing(self.h, int(on))
+
+    def kernel_ms(self, name):
+        v = C.c_float()
+        self._chk(self.lib.rmx_last_kernel_ms(self.h, name.encode(), C.byref(v)), "rmx_last_kernel_ms")
+        return v.value
+
+    def workspace_bytes(self):
+        return self.lib.rmx_ctx_workspace_bytes(self.h)
+
+    # ---- kpe -------------------------------------------------------------------------------
+    def alloc_tables(self, n):
+        t = self.torch
+        desc = t.empty((n, self.kmax, DESC_BYTES), dtype=t.uint8, device=self.device)
+        kcount = t.empty(n, dtype=t.int32, device=self.device)
+        return desc, kcount
+
+    def kpe(self, frames, median=None, desc=None, kcount=None):
+        """frames: (n, H, W) uint8 CUDA tensor.  Returns (median, desc, kcount) device tensors."""
+        t = self.torch
+        assert frames.is_cuda and frames.dtype == t.uint8 and frames.is_contiguous()
+        n = frames.shape[0]
+        assert tuple(frames.shape[1:]) == (self.H, self.W)
+        if median is None:
+            median = t.empty_like(frames)
+        if desc is None:
+            desc, kcount = self.alloc_tables(n)
+        self._chk(self.lib.rmx_kpe_batch(self.h, frames.data_ptr(), n, median.data_ptr(), desc.data_ptr(),
+                                         kcount.data_ptr()), "rmx_kpe_batch")
+        return median, desc, kcount
+
+    def kpe_status(self):
+        mk = C.c_uint32()
+        rc = self.lib.rmx_kpe_status(self.h, C.byref(mk))
+        return rc, mk.value
+
+    # ---- kpm -------------------------------------------------------------------------------
+    def kpm_seq(self, desc, kcount, halo=None):
+        t = self.torch
+        n = desc.shape[0]
+        dxdy = t.empty((n, 2), dtype=t.int32, device=self.device)
+        matched = t.empty(n, dtype=t.uint8, device=self.device)
+        hd, hk = (halo[0].data_ptr(), halo[1].data_ptr()) if halo is not None else (None, None)
+        self._chk(self.lib.rmx_kpm_seq(self.h, desc.data_ptr(), kcount.data_ptr(), n, hd, hk, dxdy.data_ptr(),
+                                       matched.data_ptr()), "rmx_kpm_seq")
+        return dxdy, matched
+
+    def frc_scan(self, dxdy, matched, first_is_start=True, carry=None):
+        t = self.torch
+        n = dxdy.shape[0]
+        pos = t.empty((n, 2), dtype=t.int32, device=self.device)
+        frag = t.empty(n, dtype=t.int32, device=self.device)
+        cp = (C.c_int32 * 2)(*(carry[0] if carry else (0, 0)))
+        cf = C.c_uint32(carry[1] if carry else 0)
+        self._chk(self.lib.rmx_frc_scan(self.h, dxdy.data_ptr(), matched.data_ptr(), n, int(first_is_start), cp,
+                                        C.byref(cf), pos.data_ptr(), frag.data_ptr()), "rmx_frc_scan")
+        return pos, frag, ((cp[0], cp[1]), cf.value)
+
+    # ---- fgm -------------------------------------------------------------------------------
+    def fgm_extent(self, pos_host):
+        pos_host = np.ascontiguousarray(pos_host, np.int32).reshape(-1, 2)
+        cw, ch = C.c_uint32(), C.c_uint32()
+        zx, zy = C.c_int32(), C.c_int32()
+        rc = self.lib.rmx_fgm_extent(pos_host.ctypes.data, len(pos_host), self.W, self.H, C.byref(cw), C.byref(ch),
+                                     C.byref(zx), C.byref(zy))
+        self._chk(rc, "rmx_fgm_extent")
+        return cw.value, ch.value, zx.value, zy.value
+
+    def fgm_blit(self, frames, pos, canvas, zero, frag_id=None, fragment=0):
+        ch, cw = canvas.shape[0], canvas.shape[1]
+        n = frames.shape[0]
+        self._chk(self.lib.rmx_fgm_blit_batch(self.h, frames.data_ptr(), pos.data_ptr(),
+                                              frag_id.data_ptr() if frag_id is not None else None, fragment, n,
+                                              canvas.data_ptr(), cw, ch, zero[0], zero[1]), "rmx_fgm_blit_batch")
+
+    def fgm_merge(self, dst, src, off):
+        self._chk(self.lib.rmx_fgm_merge(self.h, dst.data_ptr(), dst.shape[1], dst.shape[0], src.data_ptr(),
+                                         src.shape[1], src.shape[0], off[0], off[1]), "rmx_fgm_merge")
+
+    def fgm_blend(self, canvas):
+        t = self.torch
+        ch, cw = canvas.shape[0], canvas.shape[1]
+        img = t.empty((ch, cw), dtype=t.uint8, device=self.device)
+        mask = t.empty((ch, cw), dtype=t.uint8, device=self.device)
+        self._chk(self.lib.rmx_fgm_blend(self.h, canvas.data_ptr(), cw, ch, img.data_ptr(), mask.data_ptr()),
+                  "rmx_fgm_blend")
+        return img, mask
+
+
+def desc_to_numpy(desc, kcount):
+    """Device tables -> list of structured numpy arrays (one per frame)."""
+    d = desc.cpu().numpy()
+    k = kcount.cpu().numpy()
+    return [d[i, : k[i]].reshape(-1).view(DESC_DTYPE).copy() for i in range(len(k))]

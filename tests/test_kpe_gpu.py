@@ -1,0 +1,93 @@
+"""kpe parity on the GPU: HIP kernels (through the C ABI) vs the CPU oracle, bit-exact."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1, upscale2
+
+pytestmark = pytest.mark.gpu
+
+
+def run_kpe(frames, grid=(4, 2), overlap=16, kmax=4096):
+    import torch
+
+    n, H, W = frames.shape
+    ctx = L.Context(W, H, grid=grid, overlap=overlap, kmax=kmax)
+    d = torch.from_numpy(frames).cuda()
+    med, desc, kc = ctx.kpe(d)
+    rc, maxk = ctx.kpe_status()
+    assert rc == 0, (rc, maxk)
+    tabs = L.desc_to_numpy(desc, kc)
+    med = med.cpu().numpy()
+    ctx.close()
+    return med, tabs
+
+
+def check_against_oracle(frames, grid=(4, 2), overlap=16, kmax=4096, idx=None):
+    med, tabs = run_kpe(frames, grid, overlap, kmax)
+    idx = range(len(frames)) if idx is None else idx
+    for i in idx:
+        omed, odesc, k = O.orc_kpe(frames[i], grid[0], grid[1], overlap)
+        assert np.array_equal(med[i], omed), f"median differs, frame {i}"
+        assert len(tabs[i]) == k, f"keypoint count frame {i}: {len(tabs[i])} vs {k}"
+        assert tabs[i].tobytes() == odesc.tobytes(), f"descriptor table differs, frame {i}"
+
+
+@pytest.mark.parametrize("dens", [200, 40])
+def test_kpe_scroller_320x240(gpu, dens):
+    frames, _ = scroller_v1(24, dens=dens)
+    check_against_oracle(frames)
+
+
+def test_kpe_random_noise(gpu):
+    # every pixel a candidate: stresses the queue, the 5x5 path and large K
+    rng = np.random.default_rng(3)
+    frames = rng.integers(0, 16, size=(3, 64, 128), dtype=np.uint8)
+    check_against_oracle(frames, kmax=16384)
+
+
+def test_kpe_flat_and_edges(gpu):
+    frames = np.zeros((4, 48, 160), np.uint8)
+    frames[1] = 7
+    frames[2, :, 80:] = 9           # vertical edge
+    frames[3, 24:, :] = 3           # horizontal edge
+    frames[3, 10:14, 10:14] = 12
+    check_against_oracle(frames)
+
+
+def test_kpe_ragged_width_and_single_region(gpu):
+    # widths that do not divide into 62-lane groups; grid<1,1>, overlap 0 (fgs.hpp:17,85)
+    rng = np.random.default_rng(5)
+    for (H, W) in [(40, 132), (57, 260), (33, 500)]:
+        base = rng.integers(0, 16, size=(H // 8 + 1, W // 8 + 1), dtype=np.uint8)
+        img = np.kron(base, np.ones((8, 8), np.uint8))[:H, :W]
+        frames = np.stack([img, np.roll(img, 3, axis=1), np.roll(img, 5, axis=0)])
+        check_against_oracle(np.ascontiguousarray(frames), grid=(1, 1), overlap=0)
+
+
+def test_kpe_640x480_upscaled(gpu):
+    frames, _ = scroller_v1(4, dens=100)
+    check_against_oracle(upscale2(frames), idx=[0, 3])
+
+
+def test_kpe_kmax_overflow_is_reported(gpu):
+    import torch
+
+    rng = np.random.default_rng(9)
+    frames = rng.integers(0, 16, size=(2, 64, 128), dtype=np.uint8)
+    ctx = L.Context(128, 64, kmax=64)
+    ctx.kpe(torch.from_numpy(frames).cuda())
+    rc, maxk = ctx.kpe_status()
+    assert rc == -3 and maxk > 64
+    ctx.close()
+
+
+def test_kpe_many_frames_matches_single(gpu):
+    # batch result == per-frame result (frames packed across waves must not interact)
+    frames, _ = scroller_v1(40, dens=60)
+    med, tabs = run_kpe(frames)
+    for i in (0, 17, 39):
+        m1, t1 = run_kpe(frames[i:i + 1])
+        assert np.array_equal(med[i], m1[0])
+        assert tabs[i].tobytes() == t1[0].tobytes()
