@@ -37,9 +37,10 @@ typedef enum rmx_status {
 } rmx_status;
 
 /* One keypoint = one row of a frame's descriptor table.
- * code        : kpr::code, kpr.hpp:20-23 — 25 native nibbles of the 5x5 patch, row-major,
- *               pixel i in nibble i (even nibble = low half), nibble 25 = weight
- *               (kpe.hpp:342-379).
+ * code        : kpr::code, kpr.hpp:20-23 — the 25 native nibbles of the 5x5 patch plus the
+ *               weight, packed exactly as encode_keypoint does (kpe.hpp:342-379): row-major,
+ *               low nibble first, except that bytes 2 and 7 hold (next row's pixel 0) in the
+ *               low and (this row's pixel 4) in the high nibble; byte 12 = weight | p24 << 4.
  * region_mask : bit (grid_h*col + row) set for every kpr::grid region the point was added
  *               to (kpe.hpp:157-192,235-277; kpr.hpp:189-219).
  * x, y        : absolute image coordinates (mrl::point_t in kpe.hpp:228,303).
@@ -88,8 +89,8 @@ size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx);
  *   desc   : n*kmax rows; frame f's table starts at desc + f*kmax and holds kcount[f]
  *            rows in reference scan order.
  *   kcount : n uint32.
- * Asynchronous.  A frame with more than kmax keypoints keeps its first kmax rows in
- * scan order and sets the overflow flag reported by rmx_kpe_status(). */
+ * Asynchronous.  A frame with more than kmax keypoints sets the overflow flag reported by
+ * rmx_kpe_status(); its table is then incomplete (kcount[f] = kmax) and must not be used. */
 int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* median,
                   rmx_desc* desc, uint32_t* kcount);
 /* Synchronises; returns RMX_ERR_KMAX if any frame since the last call overflowed kmax and
@@ -111,6 +112,17 @@ int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k);
 int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint32_t n,
                 const rmx_desc* halo_desc, const uint32_t* halo_kcount, int32_t* dxdy,
                 uint8_t* matched);
+
+/* Synchronises; returns RMX_ERR_CAPACITY if a matcher workspace limit (groups per frame,
+ * shared codes or distinct offsets per region pair) was exceeded since the last call —
+ * the affected results are then invalid.  *flags (may be NULL) receives the limit bits. */
+int rmx_kpm_status(rmx_ctx* ctx, uint32_t* flags);
+
+/* Diagnostics: the per-region tickets (kpm::details::cast_vote, kpm.hpp:213-223; top-3
+ * offsets by count, ties in unordered_map iteration order) of the last rmx_kpm_seq call.
+ *   out : HOST, n*8*3 rmx_vote rows ([frame][region][rank]); valid = 0 pads short tickets.
+ * Synchronises. */
+int rmx_kpm_tickets(rmx_ctx* ctx, uint32_t n, rmx_vote* out);
 
 /* frc::collector::process_frame's state update (frc.hpp:109-115,124-127) as a segmented
  * prefix sum: a matched frame accumulates its offset onto the running position, an

@@ -1,7 +1,672 @@
-// kpm.hip — placeholder, filled in next
+// kpm.hip — keypoint matching on gfx950: grid/Borda variant (reference kpm.hpp:395-415).
+//
+// Three kernels per batch of descriptor tables:
+//
+//   kpm_build   one workgroup per frame.  Builds the device analogue of kpr::grid
+//               (kpr.hpp:93-223): for every region the keypoints grouped by code (groups in
+//               first-occurrence order = the order in which region::add creates map nodes,
+//               points of a group in scan order = push_back order, kpr.hpp:121-124), a hash
+//               index code -> group for the `previous.find(key)` of kpm.hpp:119, the weight
+//               counters, and the ITERATION ORDER of the region's std::unordered_map
+//               (what `for (auto& [key, curr] : current.points())`, kpm.hpp:112, walks).
+//   kpm_match   one wave per (frame pair, region) = cast_vote (kpm.hpp:213-223):
+//               count_offsets (all point pairs of every shared code, kpm.hpp:91-125) into
+//               an LDS hash of offsets, then top_offsets(…, 3) (kpm.hpp:127-159).
+//   kpm_declare one thread per pair: Borda count + declare (kpm.hpp:172-211).
+//
+// Bit-exactness.  top_offsets keeps the FIRST-ITERATED offset among equal counts
+// (kpm.hpp:138, strict >), iterating a std::unordered_map, so the ticket depends on
+// libstdc++'s node order.  That order is a deterministic function of the insertion
+// sequence and the hashes: umap_order_seq() below replays libstdc++'s
+// _M_insert_bucket_begin / _M_rehash_aux (GCC 11) on the device.  It needs the offsets in
+// the order the reference first touches them, i.e. in pair-enumeration order, which in
+// turn follows the iteration order of the current region's code map — hence the two
+// levels of emulation.  The replay only runs when the top-3 actually contains a tie; the
+// final declare() is order-independent given exact tickets.
 #include "common.h"
+
 namespace rmx {
-struct KpmWorkspace { void* p = nullptr; size_t bytes = 0; };
-inline size_t kpm_workspace_bytes(const KpmWorkspace& w) { return w.bytes; }
-inline void kpm_workspace_free(KpmWorkspace& w) { if (w.p) (void)hipFree(w.p); w.p = nullptr; w.bytes = 0; }
+
+// ---- hashes of the reference ------------------------------------------------------------------
+// kpr::code_hash, kpr.hpp:29-38 (64-bit size_t arithmetic)
+__device__ __forceinline__ uint64_t fnv_code(const uint32_t c[4]) {
+  uint64_t h = 2166136261ull;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    h ^= (uint64_t)((c[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    h *= 16777619ull;
+  }
+  return h;
 }
+// cdt::offset_hash, cdt.hpp:158-171 (int32 -> size_t sign-extends)
+__device__ __forceinline__ uint64_t fnv_offset(int32_t x, int32_t y) {
+  uint64_t h = 2166136261ull;
+  h ^= (uint64_t)(int64_t)x;
+  h *= 16777619ull;
+  h ^= (uint64_t)(int64_t)y;
+  h *= 16777619ull;
+  return h;
+}
+
+// libstdc++ _Prime_rehash_policy growth sequence for a default-constructed unordered_map
+// filled one element at a time: the table is rehashed to kUmapBuckets[l] when the element
+// count reaches the previous bucket count (measured with g++ 11.4, see
+// tests/test_umap_order.py; hashtable_c++0x.cc _M_need_rehash/_M_next_bkt).
+__device__ const uint32_t kUmapBuckets[12] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043};
+
+// Iteration order of a libstdc++ unordered_map after inserting keys with 64-bit hashes
+// h[0..n-1] in index order (oracle: orc_umap_order).  Sequential; called by ONE lane.
+// next/bucket: 16-bit scratch (next: n entries, bucket: >= final bucket count entries).
+// order[k] = index of the k-th iterated key.
+template <typename OutT>
+__device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* next, uint16_t* bucket, OutT* order) {
+  const uint32_t NONE = 0xffffu, BEFORE = 0xfffeu;
+  uint32_t head = NONE, B = 1;
+  int level = -1;
+  for (uint32_t i = 0; i < n; ++i) {
+    if (i == 0 || i == B) {
+      ++level;
+      const uint32_t Bn = kUmapBuckets[level];
+      for (uint32_t b = 0; b < Bn; ++b) bucket[b] = (uint16_t)NONE;
+      uint32_t p = head, bbegin = 0;
+      head = NONE;
+      while (p != NONE) {  // _M_rehash_aux
+        uint32_t nx = next[p];
+        uint32_t b = (uint32_t)(h[p] % Bn);
+        uint32_t before = bucket[b];
+        if (before == NONE) {
+          next[p] = (uint16_t)head;
+          head = p;
+          bucket[b] = (uint16_t)BEFORE;
+          if (next[p] != NONE) bucket[bbegin] = (uint16_t)p;
+          bbegin = b;
+        } else if (before == BEFORE) {
+          next[p] = (uint16_t)head;
+          head = p;
+        } else {
+          next[p] = next[before];
+          next[before] = (uint16_t)p;
+        }
+        p = nx;
+      }
+      B = Bn;
+    }
+    // _M_insert_bucket_begin
+    uint32_t b = (uint32_t)(h[i] % B);
+    uint32_t before = bucket[b];
+    if (before == NONE) {
+      next[i] = (uint16_t)head;
+      head = i;
+      if (next[i] != NONE) bucket[(uint32_t)(h[next[i]] % B)] = (uint16_t)i;
+      bucket[b] = (uint16_t)BEFORE;
+    } else if (before == BEFORE) {
+      next[i] = (uint16_t)head;
+      head = i;
+    } else {
+      next[i] = next[before];
+      next[before] = (uint16_t)i;
+    }
+  }
+  uint32_t k = 0;
+  for (uint32_t p = head; p != NONE; p = next[p]) order[k++] = (OutT)p;
+}
+
+// ---- per-frame region tables -----------------------------------------------------------------------
+constexpr uint32_t KPM_KMAX = 2048;     // descriptor-table stride supported by the matcher
+constexpr uint32_t KPM_GPOOL = 4096;    // groups per frame summed over regions (LDS pool)
+constexpr uint32_t KPM_BUCKETS = 2357;  // bucket scratch per region (covers 2048 groups)
+constexpr uint32_t HDR_U32 = 64;        // 8 regions x 8 words
+
+// header words per region
+enum { H_E = 0, H_G = 1, H_POFF = 2, H_GOFF = 3, H_HTOFF = 4, H_HTMASK = 5, H_W2 = 6, H_W1 = 7 };
+
+struct KpmWorkspace {
+  uint32_t* pool = nullptr;  // (n_cap + 1) frames x stride_u32
+  uint32_t* tickets = nullptr;  // n_cap pairs x 8 regions x 3 x 2 (key, count)
+  uint32_t n_cap = 0, kmax = 0;
+  size_t bytes = 0;
+};
+__host__ __device__ inline uint32_t kpm_stride_u32(uint32_t kmax) { return HDR_U32 + 4 * kmax * 4 + 8 + 16 * kmax + 128; }
+__host__ __device__ inline uint32_t kpm_off_pts(uint32_t) { return HDR_U32; }
+__host__ __device__ inline uint32_t kpm_off_gstart(uint32_t kmax) { return HDR_U32 + 4 * kmax; }
+__host__ __device__ inline uint32_t kpm_off_gfirst(uint32_t kmax) { return HDR_U32 + 8 * kmax + 8; }
+__host__ __device__ inline uint32_t kpm_off_giter(uint32_t kmax) { return HDR_U32 + 12 * kmax + 8; }
+__host__ __device__ inline uint32_t kpm_off_ht(uint32_t kmax) { return HDR_U32 + 16 * kmax + 8; }
+
+inline size_t kpm_workspace_bytes(const KpmWorkspace& w) { return w.bytes; }
+inline void kpm_workspace_free(KpmWorkspace& w) {
+  if (w.pool) (void)hipFree(w.pool);
+  if (w.tickets) (void)hipFree(w.tickets);
+  w = KpmWorkspace{};
+}
+
+struct KpmBuildParams {
+  const rmx_desc* desc;        // n tables, stride kmax
+  const uint32_t* kcount;
+  const rmx_desc* halo_desc;   // optional table of the frame before frame 0 (pool slot n)
+  const uint32_t* halo_kcount;
+  uint32_t* pool;
+  uint32_t* status;
+  uint32_t n, kmax, nreg;
+};
+
+__device__ __forceinline__ void load_code(const rmx_desc* d, uint32_t c[4]) {
+  const uint16_t* s = reinterpret_cast<const uint16_t*>(d);  // 18-byte rows, 2-byte aligned
+  c[0] = s[0] | (uint32_t)s[1] << 16;
+  c[1] = s[2] | (uint32_t)s[3] << 16;
+  c[2] = s[4] | (uint32_t)s[5] << 16;
+  c[3] = s[6] & 0xffu;
+}
+__device__ __forceinline__ bool same_code(const uint32_t a[4], const uint32_t b[4]) {
+  return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3];
+}
+
+// Exclusive prefix sum of one value per thread over a 256-thread block (LDS scratch: 8 u32).
+__device__ inline uint32_t block_exscan(uint32_t v, uint32_t* scratch, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  __syncthreads();
+  if (lane == 63) scratch[wv] = incl;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+  for (uint32_t w = 0; w < 4; ++w) {
+    uint32_t s = scratch[w];
+    if (w < wv) base += s;
+    tot += s;
+  }
+  *total = tot;
+  return base + incl - v;
+}
+
+__device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
+  for (uint32_t k = 2; k <= n2; k <<= 1) {
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+        uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          uint32_t x = a[i], y = a[ixj];
+          bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            a[i] = y;
+            a[ixj] = x;
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
+  __shared__ uint16_t ent[KPM_KMAX];       // scan indices of the region's entries, scan order
+  __shared__ uint16_t slot_of[KPM_KMAX];   // hash slot of entry i
+  __shared__ uint16_t gid_of[KPM_KMAX];    // rank of a group's first entry -> group id
+  __shared__ uint32_t htl[2 * KPM_KMAX];   // slot -> smallest entry rank with that code
+  __shared__ uint32_t keys[KPM_KMAX];
+  __shared__ uint64_t hg[KPM_GPOOL];       // group hashes in insertion order, pooled over regions
+  __shared__ uint16_t nxt[KPM_GPOOL];
+  __shared__ uint16_t bkt[8][KPM_BUCKETS + 3];
+  __shared__ uint32_t scan_scratch[8];
+  __shared__ uint32_t gl_off[9];           // region offsets into hg/nxt
+  __shared__ uint32_t gg_off[8];           // region offsets into the frame's group arrays
+  __shared__ uint32_t s_w2, s_w1;
+
+  const uint32_t fslot = blockIdx.x;  // 0..n-1 frames of the batch, n = halo
+  const bool is_halo = fslot == p.n;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
+  if (k > p.kmax) k = p.kmax;
+  uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
+  uint32_t* hdr = pool;
+  uint32_t* pts = pool + kpm_off_pts(p.kmax);
+  uint32_t* gstart = pool + kpm_off_gstart(p.kmax);
+  uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
+  uint32_t* ght = pool + kpm_off_ht(p.kmax);
+  const uint32_t tid = threadIdx.x;
+  const uint32_t EMPTY = 0xffffffffu;
+
+  uint32_t p_off = 0, g_off = 0, ht_off = 0, gl = 0;  // running pool offsets (uniform)
+  if (tid == 0) gl_off[0] = 0;
+  const uint32_t seg = (k + 255) / 256;  // contiguous entries per thread
+
+  for (uint32_t r = 0; r < p.nreg; ++r) {
+    // 1. compact the region's entries, preserving scan order
+    uint32_t cnt = 0;
+    const uint32_t i0 = tid * seg, i1 = min(k, i0 + seg);
+    for (uint32_t i = i0; i < i1; ++i) cnt += (desc[i].region_mask >> r) & 1u;
+    uint32_t e = 0;
+    uint32_t w = block_exscan(cnt, scan_scratch, &e);
+    for (uint32_t i = i0; i < i1; ++i)
+      if ((desc[i].region_mask >> r) & 1u) ent[w++] = (uint16_t)i;
+    uint32_t slots = 16;
+    while (slots < 2 * e) slots <<= 1;
+    const uint32_t mask = slots - 1;
+    for (uint32_t s = tid; s < slots; s += 256) htl[s] = EMPTY;
+    if (tid == 0) {
+      s_w2 = 0;
+      s_w1 = 0;
+    }
+    __syncthreads();
+    // 2. group by code: slot value = smallest entry rank holding that code
+    for (uint32_t i = tid; i < e; i += 256) {
+      uint32_t c[4];
+      load_code(desc + ent[i], c);
+      uint32_t wgt = c[3] & 0xfu;
+      if (wgt == 2) atomicAdd(&s_w2, 1u);
+      if (wgt == 1) atomicAdd(&s_w1, 1u);
+      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      for (;;) {
+        uint32_t v = atomicCAS(&htl[s], EMPTY, i);
+        if (v == EMPTY) break;
+        uint32_t c2[4];
+        load_code(desc + ent[v], c2);
+        if (same_code(c, c2)) {
+          atomicMin(&htl[s], i);
+          break;
+        }
+        s = (s + 1) & mask;
+      }
+      slot_of[i] = (uint16_t)s;
+    }
+    __syncthreads();
+    // 3. order entries by (first occurrence of their code, scan order)
+    uint32_t n2 = 1;
+    while (n2 < e) n2 <<= 1;
+    for (uint32_t i = tid; i < n2; i += 256) keys[i] = i < e ? (htl[slot_of[i]] << 16 | i) : 0xffffffffu;
+    bitonic_sort_u32(keys, n2);
+    // 4. groups: ids in first-occurrence order; points, starts, first indices, hashes
+    const uint32_t eseg = (e + 255) / 256;
+    const uint32_t j0 = tid * eseg, j1 = min(e, j0 + eseg);
+    uint32_t starts = 0;
+    for (uint32_t j = j0; j < j1; ++j) starts += (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16));
+    uint32_t G = 0;
+    uint32_t gid = block_exscan(starts, scan_scratch, &G);
+    const bool fits = gl + G <= KPM_GPOOL && G <= 2048;
+    for (uint32_t j = j0; j < j1; ++j) {
+      uint32_t first = keys[j] >> 16, i = keys[j] & 0xffffu;
+      const rmx_desc* d = desc + ent[i];
+      pts[p_off + j] = (uint32_t)d->x | (uint32_t)d->y << 16;
+      if (j == 0 || first != (keys[j - 1] >> 16)) {
+        gstart[g_off + r + gid] = p_off + j;
+        gfirst[g_off + gid] = ent[first];
+        gid_of[first] = (uint16_t)gid;
+        if (fits) {
+          uint32_t c[4];
+          load_code(desc + ent[first], c);
+          hg[gl + gid] = fnv_code(c);
+        }
+        ++gid;
+      }
+    }
+    __syncthreads();
+    // 5. export the code index: slot -> group id + 1
+    for (uint32_t s = tid; s < slots; s += 256) {
+      uint32_t v = htl[s];
+      ght[ht_off + s] = v == EMPTY ? 0u : (uint32_t)gid_of[v] + 1u;
+    }
+    if (tid == 0) {
+      gstart[g_off + r + G] = p_off + e;  // sentinel (one extra slot per region)
+      uint32_t* h = hdr + r * 8;
+      h[H_E] = e;
+      h[H_G] = G;
+      h[H_POFF] = p_off;
+      h[H_GOFF] = g_off;
+      h[H_HTOFF] = ht_off;
+      h[H_HTMASK] = mask;
+      h[H_W2] = s_w2;
+      h[H_W1] = s_w1;
+      if (!fits) atomicOr(&p.status[1], 1u);
+      gl_off[r + 1] = fits ? gl + G : gl;
+      gg_off[r] = g_off;
+    }
+    p_off += e;
+    g_off += G;
+    ht_off += slots;
+    if (fits) gl += G;
+    __syncthreads();
+  }
+  // 6. iteration order of every region's code map: lane r replays libstdc++ for region r
+  if (tid < p.nreg) {
+    const uint32_t r = tid;
+    const uint32_t a = gl_off[r], G = gl_off[r + 1] - a;
+    uint32_t* giter = pool + kpm_off_giter(p.kmax) + gg_off[r];
+    umap_order_seq(hg + a, G, nxt + a, bkt[r], giter);
+  }
+}
+
+// ---- matching --------------------------------------------------------------------------------------
+constexpr uint32_t KM_HSLOTS = 2048;   // offset hash slots per wave
+constexpr uint32_t KM_DMAX = 1024;     // distinct offsets per (pair, region)
+constexpr uint32_t KM_MG = 1024;       // matched code groups per (pair, region)
+
+struct KpmMatchParams {
+  const rmx_desc* desc;
+  const rmx_desc* halo_desc;
+  const uint32_t* pool;
+  uint32_t* tickets;  // pairs x nreg x 3 x {key, count}
+  uint32_t* status;
+  uint32_t n, kmax, nreg;
+  uint32_t has_halo;
+  uint32_t weight_switch;
+};
+
+__device__ __forceinline__ uint32_t off_key(int32_t dx, int32_t dy) {
+  return (uint32_t)(dx + 32768) << 16 | (uint32_t)(dy + 32768);
+}
+
+__device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    uint64_t t = (uint64_t)__shfl_xor((long long)v, o);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+// One wave per (pair, region).  Pair index q: current frame = q (q = 0 pairs the halo with
+// frame 0), previous frame = q - 1 (pool slot n for the halo).
+__global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
+  __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
+  __shared__ uint32_t mg_p[KM_MG], mg_c[KM_MG], mg_base[KM_MG + 1];
+  __shared__ uint64_t hh[KM_DMAX];
+  __shared__ uint16_t nxt[KM_DMAX], bkt[1109 + 3], pos_of[KM_DMAX];
+  __shared__ uint64_t skey[KM_DMAX];
+
+  const uint32_t lane = threadIdx.x;
+  const uint32_t q = blockIdx.x / p.nreg, r = blockIdx.x % p.nreg;
+  uint32_t* ticket = p.tickets + ((size_t)q * p.nreg + r) * 6;
+  if (lane < 6) ticket[lane] = 0;
+  if (q == 0 && !p.has_halo) return;
+  const uint32_t stride = kpm_stride_u32(p.kmax);
+  const uint32_t pslot = q == 0 ? p.n : q - 1;
+  const uint32_t* P = p.pool + (size_t)pslot * stride;
+  const uint32_t* Cc = p.pool + (size_t)q * stride;
+  const rmx_desc* pdesc = q == 0 ? p.halo_desc : p.desc + (size_t)(q - 1) * p.kmax;
+  const rmx_desc* cdesc = p.desc + (size_t)q * p.kmax;
+  const uint32_t* ph = P + r * 8;
+  const uint32_t* ch = Cc + r * 8;
+  const uint32_t Gc = ch[H_G];
+  if (Gc == 0 || ph[H_G] == 0) return;
+  // kpm.hpp:219-222: all codes unless both regions are rich in weight-2 keypoints
+  const bool use_all = ph[H_W2] < p.weight_switch || ch[H_W2] <= p.weight_switch;
+  const uint32_t* c_gstart = Cc + kpm_off_gstart(p.kmax) + ch[H_GOFF] + r;
+  const uint32_t* c_gfirst = Cc + kpm_off_gfirst(p.kmax) + ch[H_GOFF];
+  const uint32_t* c_giter = Cc + kpm_off_giter(p.kmax) + ch[H_GOFF];
+  const uint32_t* c_pts = Cc + kpm_off_pts(p.kmax);
+  const uint32_t* p_gstart = P + kpm_off_gstart(p.kmax) + ph[H_GOFF] + r;
+  const uint32_t* p_gfirst = P + kpm_off_gfirst(p.kmax) + ph[H_GOFF];
+  const uint32_t* p_ht = P + kpm_off_ht(p.kmax) + ph[H_HTOFF];
+  const uint32_t* p_pts = P + kpm_off_pts(p.kmax);
+  const uint32_t pmask = ph[H_HTMASK];
+
+  // ---- a. shared codes in the current map's iteration order, with pair-index bases ----
+  uint32_t nm = 0, total = 0;  // uniform
+  bool overflow = false;
+  for (uint32_t base = 0; base < Gc; base += 64) {
+    uint32_t pairs = 0, gp = 0, gc = 0;
+    if (base + lane < Gc) {
+      gc = c_giter[base + lane];
+      uint32_t c[4];
+      load_code(cdesc + c_gfirst[gc], c);
+      if (use_all || (c[3] & 0xfu) == 2u) {
+        uint32_t s = (uint32_t)fnv_code(c) & pmask;
+        for (;;) {
+          uint32_t v = p_ht[s];
+          if (v == 0) break;
+          uint32_t c2[4];
+          load_code(pdesc + p_gfirst[v - 1], c2);
+          if (same_code(c, c2)) {
+            gp = v - 1;
+            pairs = (p_gstart[gp + 1] - p_gstart[gp]) * (c_gstart[gc + 1] - c_gstart[gc]);
+            break;
+          }
+          s = (s + 1) & pmask;
+        }
+      }
+    }
+    uint64_t bal = __builtin_amdgcn_ballot_w64(pairs != 0);
+    uint32_t incl = pairs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= (uint32_t)o) incl += t;
+    }
+    uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
+    if (nm + cnt > KM_MG) {
+      overflow = true;
+      break;
+    }
+    if (pairs != 0) {
+      uint32_t at = nm + mbcnt(bal);
+      mg_p[at] = gp;
+      mg_c[at] = gc;
+      mg_base[at] = total + incl - pairs;
+    }
+    total += (uint32_t)__shfl((int)incl, 63);
+    nm += cnt;
+  }
+  if (overflow) {
+    if (lane == 0) atomicOr(&p.status[1], 2u);
+    return;
+  }
+  if (nm == 0) return;
+  if (lane == 0) mg_base[nm] = total;
+  for (uint32_t s = lane; s < KM_HSLOTS; s += 64) {
+    hk[s] = 0;
+    hc[s] = 0;
+    hs[s] = 0xffffffffu;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- b. count_offsets: every (previous point, current point) pair of every shared code ----
+  uint32_t my_new = 0;
+  for (uint32_t t = lane; t < total; t += 64) {
+    uint32_t lo = 0, hi = nm;  // largest g with mg_base[g] <= t
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (mg_base[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    uint32_t gp = mg_p[lo], gc = mg_c[lo], rel = t - mg_base[lo];
+    uint32_t cs = c_gstart[gc], nc = c_gstart[gc + 1] - cs;
+    uint32_t ip = rel / nc, ic = rel - ip * nc;  // previous outer, current inner (kpm.hpp:94-95)
+    uint32_t pp = p_pts[p_gstart[gp] + ip], cp = c_pts[cs + ic];
+    int32_t dx = (int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu);
+    int32_t dy = (int32_t)(pp >> 16) - (int32_t)(cp >> 16);
+    uint32_t key = off_key(dx, dy);
+    uint32_t s = (key * 2654435761u) >> 21;  // 11 bits
+    for (uint32_t probes = 0;; ++probes) {
+      uint32_t v = atomicCAS(&hk[s], 0u, key);
+      if (v == 0u) ++my_new;
+      if (v == 0u || v == key) {
+        atomicAdd(&hc[s], 1u);
+        atomicMin(&hs[s], t);
+        break;
+      }
+      s = (s + 1) & (KM_HSLOTS - 1);
+      if (probes > KM_HSLOTS) break;  // table full: flagged below through the distinct count
+    }
+  }
+  uint32_t D = my_new;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) D += (uint32_t)__shfl_xor((int)D, o);
+  if (D > KM_DMAX) {
+    if (lane == 0) atomicOr(&p.status[1], 4u);
+    return;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- c. top_offsets(total, 3): by count, ties by iteration order of the totalizator ----
+  // top-4 counts to detect whether any tie can influence the ticket
+  uint64_t best[4];
+  {
+    uint64_t taken_mask_lo = 0;  // per-lane: which of my slots were taken (slot index = lane + 64*i)
+    for (int rdx = 0; rdx < 4; ++rdx) {
+      uint64_t m = 0;
+      for (uint32_t i = 0; i < KM_HSLOTS / 64; ++i) {
+        uint32_t s = lane + 64 * i;
+        if (hk[s] != 0 && !((taken_mask_lo >> i) & 1ull)) {
+          uint64_t cand = (uint64_t)hc[s] << 32 | (uint64_t)(0xffffffffu - s);
+          m = cand > m ? cand : m;
+        }
+      }
+      uint64_t w = wave_max_u64(m);
+      best[rdx] = w;
+      if (w != 0) {
+        uint32_t s = 0xffffffffu - (uint32_t)w;
+        if ((s & 63u) == lane) taken_mask_lo |= 1ull << (s >> 6);
+      }
+    }
+  }
+  const uint32_t c1 = (uint32_t)(best[0] >> 32), c2 = (uint32_t)(best[1] >> 32), c3 = (uint32_t)(best[2] >> 32),
+                 c4 = (uint32_t)(best[3] >> 32);
+  const bool tie = (D >= 2 && c1 == c2) || (D >= 3 && c2 == c3) || (D >= 4 && c3 == c4);
+  if (!tie) {
+    if (lane < 3 && lane < D) {
+      uint32_t s = 0xffffffffu - (uint32_t)best[lane];
+      ticket[2 * lane] = hk[s];
+      ticket[2 * lane + 1] = hc[s];
+    }
+    return;
+  }
+  // exact path: insertion order of the totalizator = order of first occurrence among pairs
+  // compact distinct offsets
+  uint32_t nd = 0;
+  for (uint32_t i = 0; i < KM_HSLOTS; i += 64) {
+    uint32_t s = i + lane;
+    bool occ = hk[s] != 0;
+    uint64_t bal = __builtin_amdgcn_ballot_w64(occ);
+    if (occ) skey[nd + mbcnt(bal)] = (uint64_t)hs[s] << 32 | s;
+    nd += (uint32_t)__builtin_popcountll(bal);
+  }
+  uint32_t n2 = 1;
+  while (n2 < nd) n2 <<= 1;
+  for (uint32_t i = nd + lane; i < n2; i += 64) skey[i] = ~0ull;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < n2; i += 64) {
+        uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          uint64_t x = skey[i], y = skey[ixj];
+          bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            skey[i] = y;
+            skey[ixj] = x;
+          }
+        }
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < nd; i += 64) {
+    uint32_t s = (uint32_t)skey[i];
+    uint32_t key = hk[s];
+    hh[i] = fnv_offset((int32_t)(key >> 16) - 32768, (int32_t)(key & 0xffffu) - 32768);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  if (lane == 0) {
+    // order[k] = insertion index of the k-th iterated offset, written into nxt-sized scratch
+    umap_order_seq(hh, nd, nxt, bkt, pos_of);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // pos_of[k] = insertion index at iteration position k; pick the best three by
+  // (count desc, iteration position asc)
+  uint32_t sel_pos[3];
+  for (int rdx = 0; rdx < 3; ++rdx) {
+    uint64_t m = 0;
+    for (uint32_t kpos = lane; kpos < nd; kpos += 64) {
+      bool used = false;
+      for (int u = 0; u < rdx; ++u) used |= sel_pos[u] == kpos;
+      if (!used) {
+        uint32_t s = (uint32_t)skey[pos_of[kpos]];
+        uint64_t cand = (uint64_t)hc[s] << 32 | (uint64_t)(0xffffffffu - kpos);
+        m = cand > m ? cand : m;
+      }
+    }
+    uint64_t w = wave_max_u64(m);
+    sel_pos[rdx] = w ? 0xffffffffu - (uint32_t)w : 0xffffffffu;
+    if (w != 0 && lane == 0) {
+      uint32_t s = (uint32_t)skey[pos_of[sel_pos[rdx]]];
+      ticket[2 * rdx] = hk[s];
+      ticket[2 * rdx + 1] = hc[s];
+    }
+  }
+}
+
+struct KpmDeclareParams {
+  const uint32_t* pool;
+  const uint32_t* tickets;
+  int32_t* dxdy;
+  uint8_t* matched;
+  uint32_t n, kmax, nreg, has_halo, region_votes;
+};
+
+// kpm.hpp:395-415 tail: get_active, count (Borda), top_offsets(…, 2), declare.
+__global__ void kpm_declare(KpmDeclareParams p) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= p.n) return;
+  int32_t dx = 0, dy = 0;
+  uint8_t ok = 0;
+  if (q > 0 || p.has_halo) {
+    const uint32_t* Cc = p.pool + (size_t)q * kpm_stride_u32(p.kmax);
+    uint32_t active = 0;
+    for (uint32_t r = 0; r < p.nreg; ++r) active += Cc[r * 8 + H_E] != 0;
+    if (active >= p.nreg / 4) {
+      uint32_t keys[24], tot[24], nk = 0;
+      const uint32_t* t = p.tickets + (size_t)q * p.nreg * 6;
+      for (uint32_t r = 0; r < p.nreg; ++r) {
+        uint32_t rank = p.region_votes;
+        for (uint32_t j = 0; j < 3; ++j, --rank) {
+          uint32_t key = t[r * 6 + 2 * j];
+          if (key == 0) break;
+          uint32_t i = 0;
+          for (; i < nk; ++i)
+            if (keys[i] == key) break;
+          if (i == nk) {
+            keys[nk] = key;
+            tot[nk] = 0;
+            ++nk;
+          }
+          tot[i] += rank;
+        }
+      }
+      if (nk > 0) {
+        uint32_t b0 = 0;
+        for (uint32_t i = 1; i < nk; ++i)
+          if (tot[i] > tot[b0]) b0 = i;
+        uint32_t second = 0;
+        bool has2 = false;
+        for (uint32_t i = 0; i < nk; ++i)
+          if (i != b0) {
+            has2 = true;
+            second = tot[i] > second ? tot[i] : second;
+          }
+        if (!(has2 && tot[b0] < second + active / 2)) {
+          ok = 1;
+          dx = (int32_t)(keys[b0] >> 16) - 32768;
+          dy = (int32_t)(keys[b0] & 0xffffu) - 32768;
+        }
+      }
+    }
+  }
+  p.dxdy[2 * q] = dx;
+  p.dxdy[2 * q + 1] = dy;
+  p.matched[q] = ok;
+}
+
+}  // namespace rmx

@@ -29,7 +29,7 @@ STATUS = {0: "RMX_OK", -1: "RMX_ERR_ARG", -2: "RMX_ERR_DEVICE", -3: "RMX_ERR_KMA
 # every symbol include/remap_amd.h declares
 SYMBOLS = [
     "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
-    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
+    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms",
 ]
@@ -76,6 +76,11 @@ def load():
         return _lib
     if needs_build():
         build()
+    # torch bundles its own libamdhip64 (same SONAME as /opt/rocm's).  Import it first so that
+    # this library binds to the HIP runtime torch already loaded; two runtimes in one
+    # process do not share devices, streams or allocations.
+    import torch  # noqa: F401
+
     lib = C.CDLL(SO_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     lib.rmx_version.restype = C.c_char_p
@@ -89,6 +94,8 @@ def load():
     lib.rmx_kpe_batch.argtypes = [vp, vp, u32, vp, vp, vp]
     lib.rmx_kpe_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
+    lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
+    lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
     lib.rmx_fgm_blit_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32, i32, i32]
     lib.rmx_fgm_extent.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32),
@@ -200,6 +207,16 @@ class Context:
         self._chk(self.lib.rmx_kpm_seq(self.h, desc.data_ptr(), kcount.data_ptr(), n, hd, hk, dxdy.data_ptr(),
                                        matched.data_ptr()), "rmx_kpm_seq")
         return dxdy, matched
+
+    def kpm_status(self):
+        fl = C.c_uint32()
+        rc = self.lib.rmx_kpm_status(self.h, C.byref(fl))
+        return rc, fl.value
+
+    def kpm_tickets(self, n):
+        out = np.zeros((n, 8, 3), VOTE_DTYPE)
+        self._chk(self.lib.rmx_kpm_tickets(self.h, n, out.ctypes.data), "rmx_kpm_tickets")
+        return out
 
     def frc_scan(self, dxdy, matched, first_is_start=True, carry=None):
         t = self.torch

@@ -1,0 +1,92 @@
+"""fgm canvas kernels on the GPU vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1
+
+pytestmark = pytest.mark.gpu
+
+
+def test_extent_matches_oracle_and_is_order_independent():
+    lib = L.load()
+    rng = np.random.default_rng(2)
+    for _ in range(50):
+        n = int(rng.integers(1, 30))
+        pos = rng.integers(-700, 700, size=(n, 2)).astype(np.int32)
+        pos[0] = 0
+        ctx = type("C", (), {})()
+        import ctypes as C
+        def ext(p):
+            cw, ch, zx, zy = C.c_uint32(), C.c_uint32(), C.c_int32(), C.c_int32()
+            p = np.ascontiguousarray(p)
+            assert lib.rmx_fgm_extent(p.ctypes.data, len(p), 320, 240, C.byref(cw), C.byref(ch), C.byref(zx),
+                                      C.byref(zy)) == 0
+            return cw.value, ch.value, zx.value, zy.value
+        a = ext(pos)
+        assert a == O.orc_fgm_extent(pos, 320, 240)
+        perm = np.concatenate([[0], 1 + rng.permutation(n - 1)]).astype(int)
+        assert ext(pos[perm]) == a
+
+
+def test_blit_blend_merge(gpu):
+    import torch
+
+    frames, _ = scroller_v1(40, dens=60)
+    n, H, W = frames.shape
+    ctx = L.Context(W, H)
+    rng = np.random.default_rng(4)
+    pos = np.cumsum(rng.integers(-6, 7, size=(n, 2)), axis=0).astype(np.int32)
+    pos[0] = 0
+    cw, ch, zx, zy = ctx.fgm_extent(pos)
+    assert (cw, ch, zx, zy) == O.orc_fgm_extent(pos, W, H)
+    ocan = np.zeros((ch, cw, 16), np.uint16)
+    for i in range(n):
+        O.orc_fgm_blit(ocan, (zx, zy), frames[i], pos[i])
+    d = torch.from_numpy(frames).cuda()
+    canvas = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+    ctx.fgm_blit(d, torch.from_numpy(pos).cuda(), canvas, (zx, zy))
+    got = canvas.cpu().numpy().view(np.uint16)
+    assert np.array_equal(got, ocan)
+    # only one fragment id
+    frag = torch.from_numpy((np.arange(n) % 2).astype(np.int32)).cuda()
+    c2 = torch.zeros_like(canvas)
+    ctx.fgm_blit(d, torch.from_numpy(pos).cuda(), c2, (zx, zy), frag_id=frag, fragment=1)
+    o2 = np.zeros_like(ocan)
+    for i in range(1, n, 2):
+        O.orc_fgm_blit(o2, (zx, zy), frames[i], pos[i])
+    assert np.array_equal(c2.cpu().numpy().view(np.uint16), o2)
+    # blend
+    img, mask = ctx.fgm_blend(canvas)
+    oi, om = O.orc_fgm_blend(ocan)
+    assert np.array_equal(img.cpu().numpy(), oi) and np.array_equal(mask.cpu().numpy(), om)
+    # merge c2 into a bigger canvas at an offset
+    big = torch.zeros((ch + 50, cw + 70, 16), dtype=torch.int16, device="cuda")
+    big[5:5 + ch, 9:9 + cw] = canvas
+    ob = np.zeros((ch + 50, cw + 70, 16), np.uint16)
+    ob[5:5 + ch, 9:9 + cw] = ocan
+    ctx.fgm_merge(big, c2, (33, 21))
+    O.orc_fgm_merge(ob, o2, (33, 21))
+    assert np.array_equal(big.cpu().numpy().view(np.uint16), ob)
+    ctx.close()
+
+
+def test_blit_uint16_wraparound(gpu):
+    # > 65535 hits on one pixel/colour wrap exactly like the reference's uint16 bins (fgm.hpp:14)
+    import torch
+
+    W, H, n = 16, 8, 65536 + 5
+    frame = np.arange(W * H, dtype=np.uint8).reshape(H, W) % 16
+    ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+    d = torch.from_numpy(frame).cuda().expand(n, H, W).contiguous()
+    pos = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    canvas = torch.zeros((H, W, 16), dtype=torch.int16, device="cuda")
+    ctx.fgm_blit(d, pos, canvas, (0, 0))
+    got = canvas.cpu().numpy().view(np.uint16)
+    exp = np.zeros((H, W, 16), np.uint16)
+    for y in range(H):
+        for x in range(W):
+            exp[y, x, frame[y, x]] = n % 65536
+    assert np.array_equal(got, exp)
+    ctx.close()

@@ -1,0 +1,112 @@
+"""kpm / frc parity on the GPU: offsets, tickets (incl. libstdc++ tie order), positions."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_pipeline(frames, kmax=2048, split=None):
+    import torch
+
+    n, H, W = frames.shape
+    ctx = L.Context(W, H, kmax=kmax)
+    d = torch.from_numpy(frames).cuda()
+    med, desc, kc = ctx.kpe(d)
+    assert ctx.kpe_status()[0] == 0
+    if split is None:
+        dxdy, matched = ctx.kpm_seq(desc, kc)
+        tickets = ctx.kpm_tickets(n)
+    else:
+        a = ctx.kpm_seq(desc[:split], kc[:split])
+        ta = ctx.kpm_tickets(split)
+        b = ctx.kpm_seq(desc[split:], kc[split:], halo=(desc[split - 1], kc[split - 1:split]))
+        tb = ctx.kpm_tickets(n - split)
+        dxdy = torch.cat([a[0], b[0]])
+        matched = torch.cat([a[1], b[1]])
+        tickets = np.concatenate([ta, tb])
+    assert ctx.kpm_status()[0] == 0
+    tabs = L.desc_to_numpy(desc, kc)
+    out = dict(dxdy=dxdy.cpu().numpy(), matched=matched.cpu().numpy(), tickets=tickets, tabs=tabs, ctx=ctx,
+               dev=(dxdy, matched))
+    return out
+
+
+def check_seq(frames, **kw):
+    g = gpu_pipeline(frames, **kw)
+    n = len(frames)
+    ties = 0
+    for i in range(1, n):
+        m, d, t = O.orc_kpm_grid(g["tabs"][i - 1], g["tabs"][i])
+        gt = g["tickets"][i]
+        assert gt.tobytes() == t.tobytes(), f"tickets differ at frame {i}:\n{gt}\n{t}"
+        assert g["matched"][i] == m, f"matched differs at frame {i}"
+        assert tuple(g["dxdy"][i]) == d, f"offset differs at frame {i}: {g['dxdy'][i]} vs {d}"
+        for r in range(8):
+            c = [int(v["count"]) for v in t[r] if v["valid"]]
+            ties += any(c[j] == c[j + 1] for j in range(len(c) - 1))
+    assert g["matched"][0] == 0
+    return g, ties
+
+
+@pytest.mark.parametrize("dens", [200, 40])
+def test_kpm_scroller(gpu, dens):
+    frames, truth = scroller_v1(40, dens=dens)
+    g, ties = check_seq(frames)
+    assert (g["dxdy"][1:] == truth[1:]).all() and g["matched"][1:].all()
+    if dens == 40:
+        assert ties > 0  # the dense stream exercises the unordered_map tie order
+
+
+def test_kpm_repetitive_tiles_many_ties(gpu):
+    # a tiled world: many identical codes, large all-pairs groups, ambiguous offsets
+    rng = np.random.default_rng(11)
+    tile = rng.integers(0, 16, size=(16, 16), dtype=np.uint8)
+    tile = np.kron(tile[:4, :4], np.ones((4, 4), np.uint8))
+    world = np.tile(tile, (240 // 16 + 1, 40))[:240]
+    world[100:140, 300:340] = 3  # one unique landmark
+    frames = np.stack([world[:, x:x + 320] for x in (0, 3, 7, 8, 12, 16, 16, 21)])
+    check_seq(np.ascontiguousarray(frames))
+
+
+def test_kpm_breaks_and_blank_frames(gpu):
+    frames, _ = scroller_v1(12, dens=100)
+    frames = frames.copy()
+    frames[4] = 6            # blank frame: no keypoints -> active < 2 -> no match, and next too
+    frames[8] = frames[8][::-1].copy()  # unrelated content
+    g, _ = check_seq(frames)
+    assert g["matched"][4] == 0 and g["matched"][5] == 0
+
+
+def test_kpm_halo_equals_single_batch(gpu):
+    frames, _ = scroller_v1(30, dens=40)
+    a, _ = check_seq(frames)
+    b = gpu_pipeline(frames, split=13)
+    assert np.array_equal(a["dxdy"][1:], b["dxdy"][1:]) and np.array_equal(a["matched"][1:], b["matched"][1:])
+    assert a["tickets"][1:].tobytes() == b["tickets"][1:].tobytes()
+
+
+def test_frc_scan_matches_oracle(gpu):
+    import torch
+
+    frames, _ = scroller_v1(60, dens=100)
+    frames = frames.copy()
+    frames[20] = 6
+    frames[41] = 6
+    g = gpu_pipeline(frames)
+    ctx = g["ctx"]
+    dxdy, matched = g["dev"]
+    pos, frag, carry = ctx.frc_scan(dxdy, matched)
+    o = O.orc_frc(frames)
+    assert np.array_equal(pos.cpu().numpy(), o["pos"])
+    assert np.array_equal(frag.cpu().numpy().astype(np.uint32), o["frag"])
+    assert np.array_equal(g["matched"], o["matched"]) and np.array_equal(g["dxdy"], o["dxdy"])
+    # the same in two batches with the carry
+    p1, f1, c1 = ctx.frc_scan(dxdy[:25], matched[:25])
+    p2, f2, c2 = ctx.frc_scan(dxdy[25:], matched[25:], first_is_start=False, carry=c1)
+    assert np.array_equal(torch.cat([p1, p2]).cpu().numpy(), o["pos"])
+    assert np.array_equal(torch.cat([f1, f2]).cpu().numpy().astype(np.uint32), o["frag"])
+    assert c2 == carry
