@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — aligned frames/s of the MI355X hot path on BASELINE.json's workload.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path (kpe -> descriptor tables -> kpm -> frc position scan)
+over this rank's block of synthetic frames, already resident in HBM.  At N = 1 the workload
+is BASELINE.json configs[1]: 10 000 scroller-v1 frames of 320x240; at N > 1 every rank gets
+its own 10 000-frame block of ONE N*10 000-frame stream (weak scaling), boundary descriptor
+tables and per-frame offsets are all-gathered over RCCL, and the result is the global
+alignment.  Rank 0 prints ONE JSON line.
+
+The line also carries
+  roofline     — kpe_main (the dominant kernel): algorithmic bytes (2*W*H + 18*K per frame,
+                 SURVEY.md §8d) / its average launch time from HIP events on the launch
+                 stream, against the 8 TB/s HBM peak;
+  cpu_baseline — the reference's own frc::collector::collect (oracle/_ref, built from
+                 /root/reference by oracle/build_ref.sh) or, if that library is absent, the
+                 CPU restatement (oracle/), timed on one host core on the same frames.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+W, H = 320, 240
+FRAMES_PER_GPU = 10000
+DENS = 200
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def cpu_baseline(frames_host):
+    """Reference (or port) CPU path on one host core over `frames_host`."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import orclib as O  # oracle/: allowed here only as the reported CPU baseline
+
+    n = len(frames_host)
+    if O.ref_full() is not None:
+        t0 = time.perf_counter()
+        O.ref_frc(frames_host)
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+                "sample": f"reference frc::collector::collect (kpe+kpm+fgm blit, no-op codec, g++ -O2 -mavx2) "
+                          f"on the first {n} frames of the same stream, {dt:.1f} s"}
+    t0 = time.perf_counter()
+    O.orc_frc(frames_host)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": f"oracle/remap_oracle.cpp kpe+kpm+frc loop on the first {n} frames of the same stream, "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU")
+    ap.add_argument("--dens", type=int, default=DENS)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-frames", type=int, default=10000)
+    args = ap.parse_args()
+
+    import torch
+
+    from remap_amd import lib as L
+    from remap_amd.pipeline import Aligner, shard_range
+    from remap_amd.synth import scroller_v1
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
+    L.load()
+
+    n_local = args.frames
+    n_total = n_local * world
+    lo, hi = shard_range(n_total, rank, world)
+    # one stream for the whole job; every rank materialises only its own block
+    frames_all, truth = scroller_v1(n_total, W, H, dens=args.dens) if world == 1 else (None, None)
+    if world > 1:
+        from remap_amd.synth import scroller_world
+
+        wld, cam = scroller_world(n_total, W, H, args.dens)
+        win = np.lib.stride_tricks.sliding_window_view(wld, W, axis=1)
+        frames_host = np.ascontiguousarray(win[:, cam[lo:hi], :].transpose(1, 0, 2))
+        truth = np.zeros((n_total, 2), np.int32)
+        truth[1:, 0] = np.diff(cam)
+    else:
+        frames_host = frames_all
+    dev = torch.device("cuda", local_rank)
+    frames = torch.from_numpy(frames_host).to(dev)
+
+    al = Aligner(W, H, kmax=2048, device=local_rank, dist=dist)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = al.align(frames, n_total=n_total)
+    # correctness of what is being timed: offsets must equal the generator's ground truth
+    dx = out["dxdy"].cpu().numpy()
+    mt = out["matched"].cpu().numpy()
+    exact = bool(mt[1:].all() and (dx[1:] == truth[1:]).all())
+    ktot = int(out["kcount"].sum().item())
+
+    al.ctx.set_timing(True)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = al.align(frames, n_total=n_total)
+    barrier()
+    dt = time.perf_counter() - t0
+    ms_kpe = al.ctx.kernel_ms("kpe_main")
+    ms_parts = {k: al.ctx.kernel_ms(k) for k in ("kpe_table", "kpm_build", "kpm_match")}
+    al.ctx.set_timing(False)
+
+    # tier B: + fgm blit into the fragment canvases (reported beside the headline)
+    al.align(frames, n_total=n_total, blit=True)
+    barrier()
+    t1 = time.perf_counter()
+    nb = max(1, args.steps // 4)
+    for _ in range(nb):
+        al.align(frames, n_total=n_total, blit=True)
+    barrier()
+    dtb = time.perf_counter() - t1
+
+    tmax = torch.tensor([dt, dtb], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt, dtb = float(tmax[0]), float(tmax[1])
+
+    if rank == 0:
+        alg_bytes = 2.0 * W * H * n_local + 18.0 * ktot
+        achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
+        line = {
+            "metric": "aligned frames/s, 320x240 stream (kpe+kpm+frc), offsets bit-exact",
+            "value": n_total * args.steps / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8",
+            "data": "synthetic",
+            "config": {"workload": f"{n_local} frames 320x240 scroller-v1 (dens {args.dens}) per GPU, "
+                                   f"kpe+kpm+frc HIP kernels, inputs resident in HBM",
+                       "frames_total": n_total, "keypoints_per_frame": ktot / n_local,
+                       "parallelism": f"frame-sharded x{world}" + (" + RCCL all-gather of boundary tables/offsets"
+                                                                   if world > 1 else "")},
+            "offsets_bit_exact_vs_truth": exact,
+            "frames_per_s_with_blit": n_total * nb / dtb,
+            "kernel_ms": dict(kpe_main=ms_kpe, **ms_parts),
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "kpe_main",
+                         "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            line["cpu_baseline"] = cpu_baseline(frames_host[: min(args.cpu_frames, n_local)])
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    al.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

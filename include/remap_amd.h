@@ -192,8 +192,11 @@ int rmx_kpm_cell_pairs(rmx_ctx* ctx, const rmx_desc* const* tables,
 const char* rmx_version(void);
 /* The two 16-entry luminance-rank LUTs (cpl.hpp:163-217) the kernels use. */
 void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
-/* Average duration in milliseconds of the last rmx_kpe_batch's main kernel, measured with
- * HIP events on the context stream (0 if timing was not enabled). */
+/* Kernel timing with HIP events recorded on the context stream around each launch (no host
+ * synchronisation while recording).  rmx_set_timing(ctx, 1) opens a measurement window (and
+ * drops earlier samples); rmx_last_kernel_ms synchronises the stream and returns the AVERAGE
+ * duration in milliseconds of `kernel` ("kpe_main", "kpe_table", "kpm_build", "kpm_match",
+ * "fgm_blit") over the launches of the window (0 if none). */
 int rmx_set_timing(rmx_ctx* ctx, int enabled);
 int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms);
 

@@ -30,10 +30,14 @@ struct rmx_ctx {
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   KpmWorkspace kpm{};
   size_t ws_bytes = 0;
-  // timing
+  // timing: HIP event pairs recorded on the context stream around each kernel launch,
+  // resolved (averaged) only when rmx_last_kernel_ms is called — no host sync in between
   bool timing = false;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  float ms_kpe = 0.f, ms_table = 0.f, ms_kpm_build = 0.f, ms_kpm_match = 0.f, ms_blit = 0.f;
+  struct Track {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+  };
+  Track ms_kpe, ms_table, ms_kpm_build, ms_kpm_match, ms_blit;
   std::string err;
 };
 
@@ -82,18 +86,31 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
 
 struct Timer {
   rmx_ctx* c;
-  float* out;
-  Timer(rmx_ctx* c_, float* o) : c(c_), out(o) {
-    if (c->timing) (void)hipEventRecord(c->ev0, c->stream);
+  rmx_ctx::Track* t;
+  std::pair<hipEvent_t, hipEvent_t>* p = nullptr;
+  Timer(rmx_ctx* c_, rmx_ctx::Track* t_) : c(c_), t(t_) {
+    if (!c->timing) return;
+    if (t->used == t->ev.size()) {
+      hipEvent_t a = nullptr, b = nullptr;
+      if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+      t->ev.emplace_back(a, b);
+    }
+    p = &t->ev[t->used++];
+    (void)hipEventRecord(p->first, c->stream);
   }
   ~Timer() {
-    if (c->timing) {
-      (void)hipEventRecord(c->ev1, c->stream);
-      (void)hipEventSynchronize(c->ev1);
-      (void)hipEventElapsedTime(out, c->ev0, c->ev1);
-    }
+    if (p) (void)hipEventRecord(p->second, c->stream);
   }
 };
+
+void free_track(rmx_ctx::Track& t) {
+  for (auto& e : t.ev) {
+    (void)hipEventDestroy(e.first);
+    (void)hipEventDestroy(e.second);
+  }
+  t.ev.clear();
+  t.used = 0;
+}
 
 }  // namespace
 
@@ -138,8 +155,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   ctx->kmax = kmax;
   ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
-      hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
-      hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+      hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess) {
     delete ctx;
     return RMX_ERR_DEVICE;
   }
@@ -155,8 +171,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->status) (void)hipFree(ctx->status);
   kpm_workspace_free(ctx->kpm);
-  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
   delete ctx;
   return RMX_OK;
 }
@@ -173,24 +188,36 @@ size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx) { return ctx ? ctx->ws_bytes 
 int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   if (!ctx) return RMX_ERR_ARG;
   ctx->timing = enabled != 0;
+  // (re)start a measurement window: forget the pairs recorded so far
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) t->used = 0;
   return RMX_OK;
 }
 
 int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) {
   if (!ctx || !kernel || !ms) return RMX_ERR_ARG;
   std::string k(kernel);
+  rmx_ctx::Track* t = nullptr;
   if (k == "kpe_main")
-    *ms = ctx->ms_kpe;
+    t = &ctx->ms_kpe;
   else if (k == "kpe_table")
-    *ms = ctx->ms_table;
+    t = &ctx->ms_table;
   else if (k == "kpm_build")
-    *ms = ctx->ms_kpm_build;
+    t = &ctx->ms_kpm_build;
   else if (k == "kpm_match")
-    *ms = ctx->ms_kpm_match;
+    t = &ctx->ms_kpm_match;
   else if (k == "fgm_blit")
-    *ms = ctx->ms_blit;
+    t = &ctx->ms_blit;
   else
     return RMX_ERR_ARG;
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  double sum = 0;
+  for (size_t i = 0; i < t->used; ++i) {
+    float v = 0.f;
+    RMX_HIP(hipEventElapsedTime(&v, t->ev[i].first, t->ev[i].second));
+    sum += v;
+  }
+  *ms = t->used ? (float)(sum / (double)t->used) : 0.f;
   return RMX_OK;
 }
 

@@ -1,0 +1,161 @@
+"""Batched alignment pipeline — the host side of frc::collector::collect (reference
+frc.hpp:55-127) on top of the C ABI, for one GPU or for a frame-sharded group of GPUs.
+
+Reference loop (sequential, frc.hpp:97-122)      this driver (batched, per rank)
+  extract(frame t)                                rmx_kpe_batch(all local frames)
+  match(grid t-1, grid t)                         rmx_kpm_seq (+ halo table from rank-1)
+  position += offset | new fragment               rmx_frc_scan over the gathered offsets
+  fragment.blit(position, frame)                  rmx_fgm_blit_batch per fragment canvas
+
+Multi-GPU: the stream is cut into contiguous frame blocks, one per rank.
+kpe needs no communication.  kpm needs, per rank, the descriptor table of the frame just
+before its block: the boundary tables (last frame of every rank, kmax*18 B + count) are
+exchanged with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests).  The
+per-frame (matched, dx, dy) triples are all-gathered (9 B/frame) and every rank runs the
+segmented scan over the whole stream, so positions and fragment ids are global and
+identical on all ranks.  No other data-path collective exists.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import lib as L
+
+__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets"]
+
+
+def shard_range(n_total: int, rank: int, world: int):
+    """Contiguous block [lo, hi) of frames owned by `rank` (blocks differ by at most one)."""
+    base, rem = divmod(n_total, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_boundary_tables(last_desc, last_k, dist=None, group=None):
+    """All-gather the last frame's descriptor table of every rank.
+
+    last_desc: (kmax, 18) uint8 tensor, last_k: (1,) int32 tensor (device of the backend).
+    Returns (tables [world, kmax, 18], counts [world]).  Without torch.distributed
+    (single process) returns the inputs with a leading axis."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return last_desc[None], last_k.reshape(1)
+    import torch
+
+    world = dist.get_world_size(group)
+    tabs = torch.empty((world,) + tuple(last_desc.shape), dtype=last_desc.dtype, device=last_desc.device)
+    cnts = torch.empty((world,), dtype=last_k.dtype, device=last_k.device)
+    dist.all_gather_into_tensor(tabs, last_desc.contiguous(), group=group)
+    dist.all_gather_into_tensor(cnts, last_k.reshape(1).contiguous(), group=group)
+    return tabs, cnts
+
+
+def gather_offsets(dxdy, matched, counts, dist=None, group=None):
+    """All-gather per-frame (dx, dy, matched) of every rank's block into stream order.
+    counts: list of block sizes per rank (blocks may differ by one -> padded gather)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dxdy, matched
+    import torch
+
+    world = dist.get_world_size(group)
+    m = max(counts)
+    pack = torch.zeros((m, 3), dtype=torch.int32, device=dxdy.device)
+    pack[: dxdy.shape[0], :2] = dxdy
+    pack[: dxdy.shape[0], 2] = matched.to(torch.int32)
+    allp = torch.empty((world, m, 3), dtype=torch.int32, device=dxdy.device)
+    dist.all_gather_into_tensor(allp, pack, group=group)
+    parts = [allp[r, : counts[r]] for r in range(world)]
+    cat = torch.cat(parts)
+    return cat[:, :2].contiguous(), cat[:, 2].to(torch.uint8).contiguous()
+
+
+class Aligner:
+    """frc::collector for a batch of frames resident in HBM (one rank's block)."""
+
+    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None):
+        import torch
+
+        self.torch = torch
+        self.ctx = L.Context(width, height, grid=(4, 2), overlap=16, kmax=kmax, device=device)
+        self.W, self.H, self.kmax = width, height, kmax
+        self.dist = dist if (dist is not None and dist.is_initialized()) else None
+        self.group = group
+        self.rank = self.dist.get_rank(group) if self.dist else 0
+        self.world = self.dist.get_world_size(group) if self.dist else 1
+        self._bufs = {}
+
+    def _buf(self, name, shape, dtype):
+        t = self.torch
+        b = self._bufs.get(name)
+        if b is None or tuple(b.shape) != tuple(shape) or b.dtype != dtype:
+            b = t.empty(shape, dtype=dtype, device=self.ctx.device)
+            self._bufs[name] = b
+        return b
+
+    def align(self, frames, n_total=None, blit=False, check=True):
+        """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
+
+        Returns a dict with device tensors: median, desc, kcount (local block) and dxdy,
+        matched, pos, frag for the WHOLE stream (identical on all ranks), plus `lo`, `hi`
+        (this rank's frame range) and, if blit=True, `canvases` for the fragments that
+        have frames on this rank."""
+        t = self.torch
+        ctx = self.ctx
+        n = frames.shape[0]
+        if n_total is None:
+            n_total = n * self.world
+        lo, hi = shard_range(n_total, self.rank, self.world)
+        assert hi - lo == n, "block size does not match shard_range"
+        median = self._buf("median", frames.shape, t.uint8)
+        desc = self._buf("desc", (n, self.kmax, L.DESC_BYTES), t.uint8)
+        kcount = self._buf("kcount", (n,), t.int32)
+        ctx.kpe(frames, median, desc, kcount)
+        halo = None
+        if self.world > 1:
+            tabs, cnts = gather_boundary_tables(desc[n - 1], kcount[n - 1:n], self.dist, self.group)
+            if self.rank > 0:
+                halo = (tabs[self.rank - 1].contiguous(), cnts[self.rank - 1:self.rank].contiguous())
+        dxdy, matched = ctx.kpm_seq(desc, kcount, halo=halo)
+        if self.world > 1:
+            counts = [shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0]
+                      for r in range(self.world)]
+            dxdy, matched = gather_offsets(dxdy, matched, counts, self.dist, self.group)
+        pos, frag, carry = ctx.frc_scan(dxdy, matched)  # synchronises
+        out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
+                   lo=lo, hi=hi, nfrag=carry[1] + 1)
+        if check:
+            rc, maxk = ctx.kpe_status()
+            if rc:
+                raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
+            rc, fl = ctx.kpm_status()
+            if rc:
+                raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
+        if blit:
+            out["canvases"] = self.blit(frames, pos, frag, lo, hi)
+        return out
+
+    def blit(self, frames, pos, frag, lo, hi):
+        """fgm::fragment::blit of this rank's frames into per-fragment canvases sized from
+        the GLOBAL positions (every rank allocates the same boxes; summing the per-rank
+        canvases with uint16 wraparound gives the reference canvas, fgm.hpp:99-113)."""
+        t = self.torch
+        pos_h = pos.cpu().numpy()
+        frag_h = frag.cpu().numpy()
+        local_frags = np.unique(frag_h[lo:hi])
+        canvases = {}
+        pos_l = pos[lo:hi].contiguous()
+        frag_l = frag[lo:hi].contiguous()
+        for fid in local_frags:
+            sel = frag_h == fid
+            cw, ch, zx, zy = self.ctx.fgm_extent(pos_h[sel])
+            key = ("canvas", int(fid))
+            c = self._bufs.get(key)
+            if c is None or tuple(c.shape) != (ch, cw, 16):
+                c = t.empty((ch, cw, 16), dtype=t.int16, device=self.ctx.device)
+                self._bufs[key] = c
+            c.zero_()
+            self.ctx.fgm_blit(frames, pos_l, c, (zx, zy), frag_id=frag_l, fragment=int(fid))
+            canvases[int(fid)] = (c, (zx, zy))
+        return canvases
+
+    def close(self):
+        self.ctx.close()
