@@ -1,0 +1,227 @@
+#!/usr/bin/env python3
+"""make_golden.py — generate tests/golden/*.npz from the REFERENCE itself.
+
+Runs only where oracle/_ref/*.so exist (built by oracle/build_ref.sh from /root/reference).
+Every expected value stored here was produced by the reference's own code:
+  tier 1 (libref_strict.so, unmodified headers): LUTs, hashes, kpm grid match + tickets,
+          kpm cellular match, fgm fragment blit/extent/blend/merge;
+  tier 2 (libref_full.so, patched temporary copy — see build_ref.sh): kpe tables/medians,
+          frc::collector::collect streams, fgs::splice.
+Fixtures hold inputs (or the seed of the committed generator remap_amd/synth.py plus a
+checksum of the generated input) and expected outputs only — never reference source.
+
+    python oracle/make_golden.py          # rewrites tests/golden/
+"""
+from __future__ import annotations
+
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import orclib as O  # noqa: E402
+from remap_amd.synth import rooms_v1, scroller_v1  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def structured_image(rng, H, W, block=6):
+    base = rng.integers(0, 16, size=(H // block + 1, W // block + 1), dtype=np.uint8)
+    img = np.kron(base, np.ones((block, block), np.uint8))[:H, :W].copy()
+    # sprinkle single pixels and thin lines so weight-1 and weight-2 keypoints both occur
+    for _ in range(H * W // 150):
+        img[rng.integers(0, H), rng.integers(0, W)] = rng.integers(0, 16)
+    return img
+
+
+def main():
+    assert O.ref_strict() is not None and O.ref_full() is not None, "run oracle/build_ref.sh first"
+    os.makedirs(OUT, exist_ok=True)
+    rng = np.random.default_rng(20261003)
+    S = O.ref_strict()
+
+    # ---- LUTs and hashes (tier 1) -------------------------------------------------------------
+    n2o = np.zeros(16, np.uint8)
+    o2n = np.zeros(16, np.uint8)
+    S.ref_luts(O.ptr(n2o), O.ptr(o2n))
+    codes = rng.integers(0, 256, size=(8, 13), dtype=np.uint8)
+    offs = np.array([[0, 0], [1, 0], [-1, 0], [3, -7], [-320, 240], [32767, -32767], [5, 5], [-2, 117]], np.int32)
+    code_h = [int(S.ref_hash_code(O.ptr(np.ascontiguousarray(c)))) for c in codes]
+    off_h = [int(S.ref_hash_offset(int(x), int(y))) for x, y in offs]
+    json.dump({"native_to_ordered": n2o.tolist(), "ordered_to_native": o2n.tolist(),
+               "hash_codes": codes.tolist(), "hash_code_values": code_h,
+               "hash_offsets": offs.tolist(), "hash_offset_values": off_h},
+              open(os.path.join(OUT, "luts_hashes.json"), "w"), indent=1)
+
+    # ---- kpe (tier 2) ---------------------------------------------------------------------------
+    kpe = {}
+    imgs = [structured_image(rng, 48, 128), structured_image(rng, 64, 160, 9), structured_image(rng, 37, 132, 5),
+            rng.integers(0, 16, size=(24, 64), dtype=np.uint8)]
+    fr, _ = scroller_v1(3, dens=40)
+    imgs.append(fr[2])
+    # hand-made 5x5 facts: the survey's verified patch at several places
+    hand = np.full((40, 128), 6, np.uint8)
+    patch = np.array([[6, 6, 6, 6, 6], [6, 2, 2, 2, 6], [6, 2, 5, 2, 6], [6, 2, 2, 2, 6], [6, 6, 6, 6, 6]], np.uint8)
+    for (y, x) in [(10, 10), (20, 80), (4, 60), (30, 100), (33, 3)]:
+        hand[y - 2:y + 3, x - 2:x + 3] = patch
+    imgs.append(hand)
+    for i, img in enumerate(imgs):
+        for single in (0, 1):
+            if single and img.shape[1] < 64:
+                continue
+            # the 4x2 band arithmetic (kpe.hpp:84-90) leaves the frame below 112x30: the
+            # reference then reads outside its scratch matrix, so such sizes are not vectors
+            if not single and (img.shape[1] < 112 or img.shape[0] < 30):
+                continue
+            med, desc, k = O.ref_kpe(img, bool(single))
+            kpe[f"img{i}"] = img
+            kpe[f"med{i}_{single}"] = med
+            kpe[f"desc{i}_{single}"] = desc.view(np.uint8).reshape(-1, 18)
+    np.savez_compressed(os.path.join(OUT, "kpe_cases.npz"), **kpe)
+
+    # ---- kpm grid variant (tier 1) ---------------------------------------------------------------
+    kpm = {}
+    ci = 0
+    for dens, nfr in ((40, 10), (200, 6), (25, 5)):
+        fr, _ = scroller_v1(nfr, dens=dens)
+        tabs = [O.ref_kpe(f)[1] for f in fr]
+        for i in range(1, nfr):
+            m, d, t = O.ref_kpm_grid(tabs[i - 1], tabs[i])
+            kpm[f"prev{ci}"] = tabs[i - 1].view(np.uint8).reshape(-1, 18)
+            kpm[f"cur{ci}"] = tabs[i].view(np.uint8).reshape(-1, 18)
+            kpm[f"res{ci}"] = np.array([m, d[0], d[1]], np.int32)
+            kpm[f"tick{ci}"] = t.view(np.uint32).reshape(8, 3, 4)
+            ci += 1
+    # degenerate pairs: empty tables, one active region only, unrelated frames
+    empty = np.zeros(0, O.DESC_DTYPE)
+    some = O.ref_kpe(scroller_v1(2, dens=40)[0][1])[1]
+    one_region = some[some["region_mask"] == 1]
+    other = O.ref_kpe(structured_image(rng, 240, 320, 11))[1]
+    for a, b in ((empty, some), (some, empty), (empty, empty), (one_region, one_region), (some, other), (some, some)):
+        m, d, t = O.ref_kpm_grid(a, b)
+        kpm[f"prev{ci}"] = a.view(np.uint8).reshape(-1, 18)
+        kpm[f"cur{ci}"] = b.view(np.uint8).reshape(-1, 18)
+        kpm[f"res{ci}"] = np.array([m, d[0], d[1]], np.int32)
+        kpm[f"tick{ci}"] = t.view(np.uint32).reshape(8, 3, 4)
+        ci += 1
+    kpm["n"] = np.array(ci)
+    np.savez_compressed(os.path.join(OUT, "kpm_grid_cases.npz"), **kpm)
+
+    # ---- fgm fragment (tier 1) -------------------------------------------------------------------
+    fgm = {}
+    fr, _ = scroller_v1(8, width=64, height=32, dens=30)
+    for case, poss in enumerate([
+        [(0, 0), (3, 0), (5, 1), (70, 2), (-3, -1), (-65, 33), (10, -40), (64, 32)],
+        [(0, 0), (0, 0), (1, 1), (2, 2), (-1, -1), (-64, -32), (128, 64), (-1, 63)],
+    ]):
+        f = O.RefFragment(64, 32)
+        trace = []
+        for i, p in enumerate(poss):
+            f.blit(p, fr[i], i)
+            trace.append(f.info()[:4])
+        img, mask = f.blend()
+        fgm[f"pos{case}"] = np.array(poss, np.int32)
+        fgm[f"trace{case}"] = np.array(trace, np.int64)
+        fgm[f"dots{case}"] = f.dots()
+        fgm[f"blend_img{case}"] = img
+        fgm[f"blend_mask{case}"] = mask
+    # merge: dst.blit(pos, std::move(src)) then normalize (fgs.hpp:170-171)
+    a = O.RefFragment(64, 32)
+    b = O.RefFragment(64, 32)
+    for i in range(4):
+        a.blit((3 * i, i), fr[i], i)
+        b.blit((-2 * i, 2 * i), fr[4 + i], 4 + i)
+    fgm["merge_a_dots"] = a.dots()
+    fgm["merge_b_dots"] = b.dots()
+    fgm["merge_a_info"] = np.array(a.info()[:4], np.int64)
+    fgm["merge_b_info"] = np.array(b.info()[:4], np.int64)
+    az = a.info()[2:4]
+    a.merge((az[0] + 37, az[1] - 11), b)
+    a.normalize()
+    fgm["merge_at"] = np.array([37, -11], np.int32)
+    fgm["merge_dots"] = a.dots()
+    fgm["merge_info"] = np.array(a.info()[:4], np.int64)
+    nums, fpos = a.frames()
+    fgm["merge_frame_numbers"] = nums
+    fgm["merge_frame_pos"] = fpos
+    fgm["frames"] = fr
+    np.savez_compressed(os.path.join(OUT, "fgm_cases.npz"), **fgm)
+
+    # ---- frc streams (tier 2): config 1 and a dense / broken stream -------------------------------
+    frc = {}
+    for name, (n, dens) in {"config1": (100, 200), "dense": (60, 40)}.items():
+        fr, truth = scroller_v1(n, dens=dens)
+        if name == "dense":
+            fr = fr.copy()
+            fr[20] = 6   # blank frame -> fragment break
+            fr[41] = 6
+        r = O.ref_frc(fr)
+        frc[f"{name}_n"] = np.array([n, dens])
+        frc[f"{name}_input_sha256"] = np.frombuffer(bytes.fromhex(sha(fr)), np.uint8)
+        frc[f"{name}_frag"] = r["frag"]
+        frc[f"{name}_pos_norm"] = r["pos_norm"]
+        frc[f"{name}_dims"] = r["dims"]
+        frc[f"{name}_canvas_sum"] = r["canvas_sum"]
+        frc[f"{name}_kentries"] = r["kentries"]
+        frc[f"{name}_truth"] = truth
+    np.savez_compressed(os.path.join(OUT, "frc_streams.npz"), **frc)
+
+    # ---- kpm cellular variant (tier 1) + fgs::splice (tier 2) -------------------------------------
+    cell = {}
+    ci = 0
+    fr, room, cam = rooms_v1(90, width=128, height=96, n_rooms=2, dens=40, seed=3)
+    # fragments as the splice stage sees them: blend of a canvas, single-region tables
+    segs = []
+    start = 0
+    for i in range(len(fr) + 1):
+        if i == len(fr) or room[i] < 0:
+            if i - start >= 2:
+                segs.append((start, i))
+            start = i + 1
+    frags = []
+    for (s, e) in segs[:4]:
+        f = O.RefFragment(128, 96)
+        for i in range(s, e):
+            f.blit((int(cam[i, 0] - cam[s, 0]), int(cam[i, 1] - cam[s, 1])), fr[i], i)
+        f.normalize()
+        img, mask = f.blend()
+        _, desc, _ = O.ref_kpe(img, True)
+        frags.append((img, mask, desc))
+    for i in range(len(frags)):
+        for j in range(len(frags)):
+            if i == j:
+                continue
+            m, v = O.ref_kpm_cell(frags[i][2], frags[i][1], frags[j][2], frags[j][1].shape)
+            cell[f"res{ci}"] = np.array([m, v["dx"], v["dy"], v["count"], i, j], np.int64)
+            ci += 1
+    for i, (img, mask, desc) in enumerate(frags):
+        cell[f"img{i}"] = img
+        cell[f"mask{i}"] = mask
+        cell[f"desc{i}"] = desc.view(np.uint8).reshape(-1, 18)
+    cell["nfrag"] = np.array(len(frags))
+    cell["npairs"] = np.array(ci)
+    np.savez_compressed(os.path.join(OUT, "kpm_cell_cases.npz"), **cell)
+
+    sp = O.ref_frc_splice(fr)
+    np.savez_compressed(os.path.join(OUT, "fgs_splice.npz"), input_sha256=np.frombuffer(bytes.fromhex(sha(fr)), np.uint8),
+                        gen=np.array([90, 128, 96, 2, 40, 3]), nfrag=np.array(sp["nfrag"]),
+                        ncollected=np.array(sp["ncollected"]), frag=sp["frag"], pos=sp["pos"], dims=sp["dims"],
+                        canvas_sum=sp["canvas_sum"])
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", OUT, f"({tot / 1024:.0f} KiB)")
+    print("fgs: collected", sp["ncollected"], "-> spliced", sp["nfrag"], "dims", sp["dims"].tolist())
+    print("cell pairs:", [cell[f"res{i}"].tolist() for i in range(ci)])
+
+
+if __name__ == "__main__":
+    main()

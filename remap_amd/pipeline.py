@@ -42,10 +42,13 @@ def gather_boundary_tables(last_desc, last_k, dist=None, group=None):
     import torch
 
     world = dist.get_world_size(group)
-    tabs = torch.empty((world,) + tuple(last_desc.shape), dtype=last_desc.dtype, device=last_desc.device)
-    cnts = torch.empty((world,), dtype=last_k.dtype, device=last_k.device)
-    dist.all_gather_into_tensor(tabs, last_desc.contiguous(), group=group)
-    dist.all_gather_into_tensor(cnts, last_k.reshape(1).contiguous(), group=group)
+    # one flat buffer per rank: [count (4 bytes, little endian) | table bytes]
+    flat = torch.cat([last_k.reshape(1).to(torch.int32).view(torch.uint8), last_desc.reshape(-1)])
+    allf = torch.empty((world * flat.numel(),), dtype=torch.uint8, device=flat.device)
+    dist.all_gather_into_tensor(allf, flat.contiguous(), group=group)
+    allf = allf.view(world, -1)
+    cnts = allf[:, :4].contiguous().view(torch.int32).reshape(world)
+    tabs = allf[:, 4:].reshape((world,) + tuple(last_desc.shape))
     return tabs, cnts
 
 
@@ -61,8 +64,9 @@ def gather_offsets(dxdy, matched, counts, dist=None, group=None):
     pack = torch.zeros((m, 3), dtype=torch.int32, device=dxdy.device)
     pack[: dxdy.shape[0], :2] = dxdy
     pack[: dxdy.shape[0], 2] = matched.to(torch.int32)
-    allp = torch.empty((world, m, 3), dtype=torch.int32, device=dxdy.device)
+    allp = torch.empty((world * m, 3), dtype=torch.int32, device=dxdy.device)
     dist.all_gather_into_tensor(allp, pack, group=group)
+    allp = allp.view(world, m, 3)
     parts = [allp[r, : counts[r]] for r in range(world)]
     cat = torch.cat(parts)
     return cat[:, :2].contiguous(), cat[:, 2].to(torch.uint8).contiguous()

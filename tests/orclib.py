@@ -134,6 +134,13 @@ def orc_umap_order(hashes):
     return o
 
 
+def orc_umap_order_std(hashes):
+    h = np.ascontiguousarray(hashes, np.uint64)
+    o = np.zeros(len(h), np.uint32)
+    oracle().orc_umap_order_std(ptr(h), len(h), ptr(o))
+    return o
+
+
 def orc_frc(frames):
     frames = np.ascontiguousarray(frames, np.uint8)
     n, H, W = frames.shape

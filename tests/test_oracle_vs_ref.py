@@ -1,0 +1,72 @@
+"""Randomised comparison of the CPU oracle with the reference's own code (oracle/_ref,
+built by oracle/build_ref.sh).  Skipped where the reference libraries are absent (they
+do not exist on a checkout without /root/reference; the golden vectors cover that case)."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd.synth import scroller_v1
+
+pytestmark = pytest.mark.skipif(O.ref_strict() is None or O.ref_full() is None,
+                                reason="oracle/_ref not built (needs /root/reference)")
+
+
+def structured(rng, H, W, block):
+    base = rng.integers(0, 16, size=(H // block + 1, W // block + 1), dtype=np.uint8)
+    img = np.kron(base, np.ones((block, block), np.uint8))[:H, :W].copy()
+    for _ in range(H * W // 100):
+        img[rng.integers(0, H), rng.integers(0, W)] = rng.integers(0, 16)
+    return img
+
+
+def test_kpe_random_images():
+    rng = np.random.default_rng(100)
+    for (H, W, b) in [(30, 112, 4), (64, 200, 7), (100, 324, 13), (240, 320, 3), (55, 128, 2)]:
+        img = structured(rng, H, W, b)
+        for single in (False, True):
+            a = O.orc_kpe(img, *((1, 1, 0) if single else (4, 2, 16)))
+            r = O.ref_kpe(img, single)
+            assert a[2] == r[2] and np.array_equal(a[0], r[0]) and a[1].tobytes() == r[1].tobytes(), (H, W, single)
+
+
+def test_kpm_grid_random_pairs():
+    rng = np.random.default_rng(101)
+    imgs = [structured(rng, 240, 320, b) for b in (5, 5, 9)]
+    tabs = [O.orc_kpe(i)[1] for i in imgs]
+    tabs.append(O.orc_kpe(np.roll(imgs[0], 3, axis=1))[1])
+    tabs.append(O.orc_kpe(np.roll(imgs[0], (2, -1), axis=(0, 1)))[1])
+    for a in range(len(tabs)):
+        for b in range(len(tabs)):
+            x, y = O.orc_kpm_grid(tabs[a], tabs[b]), O.ref_kpm_grid(tabs[a], tabs[b])
+            assert x[0] == y[0] and x[1] == y[1] and x[2].tobytes() == y[2].tobytes(), (a, b)
+
+
+def test_frc_stream_with_breaks():
+    fr, _ = scroller_v1(50, dens=60)
+    fr = fr.copy()
+    fr[17] = 6
+    o, r = O.orc_frc(fr), O.ref_frc(fr)
+    assert np.array_equal(o["frag"], r["frag"])
+    for f in range(r["nfrag"]):
+        sel = o["frag"] == f
+        cw, ch, zx, zy = O.orc_fgm_extent(o["pos"][sel], 320, 240)
+        assert [cw, ch] == r["dims"][f].tolist()
+        assert np.array_equal(o["pos"][sel] - [zx, zy], r["pos_norm"][sel])
+
+
+def test_fragment_random_blits():
+    rng = np.random.default_rng(102)
+    fr, _ = scroller_v1(12, width=64, height=32, dens=30)
+    f = O.RefFragment(64, 32)
+    pos = np.cumsum(rng.integers(-40, 41, size=(12, 2)), axis=0).astype(np.int32)
+    pos[0] = 0
+    for i in range(12):
+        f.blit(pos[i], fr[i], i)
+        assert O.orc_fgm_extent(pos[: i + 1], 64, 32) == f.info()[:4]
+    cw, ch, zx, zy = f.info()[:4]
+    can = np.zeros((ch, cw, 16), np.uint16)
+    for i in range(12):
+        O.orc_fgm_blit(can, (zx, zy), fr[i], pos[i])
+    assert np.array_equal(can, f.dots())
+    a, b = O.orc_fgm_blend(can), f.blend()
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
