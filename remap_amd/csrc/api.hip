@@ -26,6 +26,7 @@ struct rmx_ctx {
   // workspace (device)
   RawDesc* raw = nullptr;
   uint32_t* kraw = nullptr;
+  uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t n_cap = 0;
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   KpmWorkspace kpm{};
@@ -37,7 +38,7 @@ struct rmx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
   };
-  Track ms_kpe, ms_table, ms_kpm_build, ms_kpm_match, ms_blit;
+  Track ms_kpe, ms_finish, ms_table, ms_kpm_build, ms_kpm_match, ms_blit;
   std::string err;
 };
 
@@ -74,13 +75,17 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   if (n <= ctx->n_cap) return RMX_OK;
   if (ctx->raw) (void)hipFree(ctx->raw);
   if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->cand) (void)hipFree(ctx->cand);
   ctx->raw = nullptr;
   ctx->kraw = nullptr;
+  ctx->cand = nullptr;
   ctx->n_cap = 0;
+  const size_t cand_bytes = (size_t)n * ((ctx->H + 7) / 8) * (ctx->W / 4) * sizeof(uint32_t);
   RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
   RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
+  RMX_HIP(hipMalloc(&ctx->cand, cand_bytes));
   ctx->n_cap = n;
-  ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + kpm_workspace_bytes(ctx->kpm);
+  ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + cand_bytes + kpm_workspace_bytes(ctx->kpm);
   return RMX_OK;
 }
 
@@ -169,9 +174,10 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->raw) (void)hipFree(ctx->raw);
   if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->status) (void)hipFree(ctx->status);
   kpm_workspace_free(ctx->kpm);
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
   delete ctx;
   return RMX_OK;
 }
@@ -190,7 +196,7 @@ int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   ctx->timing = enabled != 0;
   // (re)start a measurement window: forget the pairs recorded so far
   RMX_HIP(hipStreamSynchronize(ctx->stream));
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) t->used = 0;
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) t->used = 0;
   return RMX_OK;
 }
 
@@ -200,6 +206,8 @@ int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) {
   rmx_ctx::Track* t = nullptr;
   if (k == "kpe_main")
     t = &ctx->ms_kpe;
+  else if (k == "kpe_finish")
+    t = &ctx->ms_finish;
   else if (k == "kpe_table")
     t = &ctx->ms_table;
   else if (k == "kpm_build")
@@ -239,15 +247,24 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   p.Wd = ctx->W / 4;
   p.V = (uint64_t)n * p.Wd;
   p.groups = (uint32_t)((p.V + 61) / 62);
-  // strips: enough waves to fill the chip for small batches, long strips for big ones
-  uint32_t rps = 60;
-  while (rps > 12 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 12;
+  // strips (multiples of 8 rows): enough waves to fill the chip for small batches, long
+  // strips (less halo-row re-reading) for big ones
+  uint32_t rps = 48;
+  while (rps > 8 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 8;
   p.rows_per_strip = rps;
   p.kmax = ctx->kmax;
+  p.cand = ctx->cand;
+  p.HB = (ctx->H + 7) / 8;
   dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
   {
     Timer t(ctx, &ctx->ms_kpe);
     hipLaunchKernelGGL(kpe_main, grid, dim3(256), 0, ctx->stream, p);
+  }
+  RMX_HIP(hipGetLastError());
+  {
+    Timer t(ctx, &ctx->ms_finish);
+    const uint32_t cpf = (p.HB * p.Wd + 255) / 256;
+    hipLaunchKernelGGL(kpe_finish, dim3(n * cpf), dim3(256), 0, ctx->stream, p);
   }
   RMX_HIP(hipGetLastError());
   TableParams tp{};

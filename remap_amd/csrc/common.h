@@ -35,14 +35,18 @@ __device__ __forceinline__ uint32_t perm(uint32_t s0, uint32_t s1, uint32_t sel)
 }
 
 // Map four packed pixels (one 0..15 value per byte) through a 16-entry byte table given as
-// four dwords (entries 0-3, 4-7, 8-11, 12-15): 8 VALU ops per 4 pixels.
+// four dwords (entries 0-3, 4-7, 8-11, 12-15): 7 full-rate VALU ops per 4 pixels.
+// Two v_perm lookups (entries 0-7 / 8-15) are merged under a byte mask that replicates
+// bit 3 of every pixel; the mask itself is one more v_perm using the sign-replicate
+// selectors (8..11) on the pixels shifted so that bit 3 sits in a byte's sign position.
 template <uint32_t T0, uint32_t T1, uint32_t T2, uint32_t T3>
 __device__ __forceinline__ uint32_t map16(uint32_t w) {
   uint32_t sel = w & 0x07070707u;
   uint32_t a = perm(T1, T0, sel);
   uint32_t b = perm(T3, T2, sel);
-  uint32_t m1 = (w >> 3) & 0x01010101u;
-  uint32_t m = (m1 << 8) - m1;  // 0xff in every byte whose value is >= 8
+  // byte i of m = 0xff iff bit 3 of byte i of w: bytes 1,3 from S1 = w << 4 (selectors 8, 9),
+  // bytes 0,2 from S0 = w << 12 (selectors 10, 11)
+  uint32_t m = perm(w << 12, w << 4, 0x090b080au);
   return (b & m) | (a & ~m);
 }
 __device__ __forceinline__ uint32_t map_key(uint32_t w) { return map16<key4(0), key4(4), key4(8), key4(12)>(w); }

@@ -15,10 +15,13 @@
 //         med3( max3(A.lo,B.lo,C.md), med3(A.md,B.md,C.hi), med3(A.hi,B.hi,C.lo) )
 //     which equals the 4th largest of the nine (exhaustively verified over the 0/1
 //     principle, tests/test_rank_network.py) — 7 VALU ops per pixel;
-//   * pixels whose centre differs from that value (rare) are compacted through a per-wave
-//     LDS queue and finished 64 at a time: the 5x5 window is gathered from L1/L2, the
-//     12th-largest-of-25 (median_pixel(H5, 12)) is found by a 4-step binary search with
-//     SWAR byte compares + v_sad_u8 counting, and keypoints are encoded and appended.
+//   * pixels whose centre differs from that value (1-8 % on the synthetic streams) are
+//     flagged in a 1-bit-per-pixel candidate plane; a second kernel (kpe_finish) hands the
+//     set bits out densely, 256 at a time: the 5x5 window is gathered from L2 / Infinity
+//     Cache, the 12th-largest-of-25 (median_pixel(H5, 12)) is found by a 4-step binary
+//     search with SWAR byte compares + v_sad_u8 counting, and keypoints are encoded and
+//     appended.  Keeping this divergent, latency-bound work out of the streaming kernel
+//     lets kpe_main run at 8 waves/SIMD with nothing but one load and one store per row.
 //
 // Work decomposition: a lane owns one dword (4 pixels) of a row and walks down a strip of
 // rows keeping three rows of sorted triples in registers; horizontally adjacent pixels
@@ -27,8 +30,8 @@
 // so waves stay full for any frame width; pixels whose window would cross a frame edge
 // are exactly the border pixels the reference never processes.
 //
-// HBM traffic: every frame byte is read once (+3 % halo re-reads served by L2), every
-// median byte written once, 32 B per keypoint.
+// HBM traffic of kpe_main: every frame byte is read once (+3 % halo re-reads served by L2),
+// every median byte written once, plus 1 bit per pixel of candidate plane (+6 %).
 #include "common.h"
 
 namespace rmx {
@@ -42,17 +45,21 @@ struct KpeParams {
   uint32_t n, W, H, Wd;
   uint64_t V;        // n * Wd virtual dword columns
   uint32_t groups;   // ceil(V / 62)
-  uint32_t rows_per_strip;
+  uint32_t rows_per_strip;  // multiple of 8
   uint32_t kmax;
+  uint32_t* cand;    // candidate bit plane: n * HB * Wd dwords
+  uint32_t HB;       // ceil(H / 8)
 };
 
 #ifndef RMX_XLANE_SHFL
 // DPP wave shifts (GFX9 family): wave_shr:1 -> lane i reads lane i-1; wave_shl:1 -> lane i+1.
+// Lanes without a source (lane 0 / lane 63) read 0: they are halo lanes whose own results
+// are never stored.
 __device__ __forceinline__ uint32_t xlane_prev(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
 }
 __device__ __forceinline__ uint32_t xlane_next(uint32_t v) {
-  return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false);
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
 }
 #else
 __device__ __forceinline__ uint32_t xlane_prev(uint32_t v) { return (uint32_t)__shfl_up((int)v, 1); }
@@ -93,10 +100,9 @@ __device__ __forceinline__ uint32_t merge_rows(const RowT& A, const RowT& B, con
     uint32_t c = umed3(A.hi[j], B.hi[j], C.lo[j]);
     r[j] = umed3(a, b, c);
   }
-  return r[0] | r[1] << 8 | r[2] << 16 | r[3] << 24;
+  uint32_t lo = r[1] << 8 | r[0], hi = r[3] << 8 | r[2];  // v_lshl_or_b32 x3
+  return hi << 16 | lo;
 }
-
-constexpr int QCAP = 128;
 
 // [b0|b1<<4, b2|b3<<4] of a dword of four nibble-valued bytes, as a 16-bit value.
 __device__ __forceinline__ uint32_t nib16(uint32_t w) {
@@ -104,16 +110,134 @@ __device__ __forceinline__ uint32_t nib16(uint32_t w) {
   return perm(0u, t, 0x0c0c0200u);
 }
 
-// Finish up to 64 queued candidate pixels (one per lane): 5x5 rank, weight, encode, append.
-// Reference: compute_pixel second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379).
-__device__ __forceinline__ void finish_candidates(const KpeParams& p, uint32_t exy, uint32_t ef, bool active) {
-  uint32_t x = exy & 0xffffu, y = exy >> 16, f = ef & 0x0fffffffu, p3 = ef >> 28;
+// Wave-uniform raw buffer descriptor (T8/T20 of the CDNA guide): 32-bit per-lane offsets,
+// hardware range check (an out-of-range lane's store is dropped, its load returns 0), so
+// the row loop needs neither 64-bit address arithmetic nor exec-masked branches.
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+
+// ---- kernel 1: streaming pass -------------------------------------------------------------------
+// frames -> median + candidate bit plane (1 bit per pixel: centre != 4th largest of 3x3).
+// Candidate word layout: one dword per (frame, 8-row block yb, dword column c); bit
+// 8*j + ((r + 4) & 7) flags pixel x = 4c + j, y = 8*yb + r.
+__global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+
+  // XCD-aware block remap (bijective): blocks that share an XCD get neighbouring groups.
+  const uint32_t nb = gridDim.x, bid = blockIdx.x;
+  const uint32_t bq = nb >> 3, br = nb & 7u, xcd = bid & 7u;
+  const uint32_t lb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (bid >> 3);
+  const uint32_t g = lb * 4 + wv;
+  if (g >= p.groups) return;  // whole wave; no block-level barriers are used below
+
+  // virtual dword column of this lane; lanes 0 and 63 are halo lanes
+  const int64_t L0 = (int64_t)g * 62 - 1;  // wave-uniform
+  const int64_t L = L0 + (int64_t)lane;
+  const bool lane_ok = lane >= 1 && lane <= 62 && L >= 0 && L < (int64_t)p.V;
+  const uint64_t Lc = L < 0 ? 0 : (L >= (int64_t)p.V ? p.V - 1 : (uint64_t)L);
+  const uint32_t f = (uint32_t)(Lc / p.Wd), c = (uint32_t)(Lc % p.Wd);
+  // wave-uniform base = first byte of the frame holding the wave's first (clamped) column
+  const uint64_t Lb = L0 < 0 ? 0 : (uint64_t)L0;
+  const uint32_t f0 = (uint32_t)(Lb / p.Wd);
+  const size_t frame_bytes = (size_t)p.W * p.H;
+  const uint32_t voff = (uint32_t)((size_t)(f - f0) * frame_bytes) + c * 4;  // < 3 frames
+  const rsrc_t rin = make_rsrc(p.frames + (size_t)f0 * frame_bytes, 0x7fffffffu);
+  const rsrc_t rout = make_rsrc(p.median + (size_t)f0 * frame_bytes, 0x7fffffffu);
+  const rsrc_t rcand = make_rsrc(p.cand + (size_t)f0 * p.HB * p.Wd, 0x7fffffffu);
+  const uint32_t voff_st = lane_ok ? voff : 0xffffffffu;  // dropped by the range check
+  const uint32_t voff_c = lane_ok ? ((f - f0) * p.HB * p.Wd + c) * 4 : 0xffffffffu;
+
+  // per-pixel x validity: processed x in [2, W-3] (kpe.hpp:183-184)
+  uint32_t maskx = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    uint32_t x = c * 4 + j;
+    if (x >= 2 && x + 3 <= p.W) maskx |= 0x0fu << (8 * j);
+  }
+  if (!lane_ok) maskx = 0;
+
+  const int H = (int)p.H, W = (int)p.W;
+  const int y0 = (int)(blockIdx.y * p.rows_per_strip);  // multiple of 8
+  const int y1 = min(H, y0 + (int)p.rows_per_strip);
+  const int vy0 = max(y0, 2), vy1 = min(y1, H - 4);  // processed rows: [2, H-5] (kpe.hpp:268)
+  auto load_row = [&](int y) -> uint32_t {
+    return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, voff, (uint32_t)(y * W), 0);
+  };
+  auto store_row = [&](int y, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, (uint32_t)(y * W), 0);
+  };
+  auto store_cand = [&](int yb, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, rcand, voff_c, (uint32_t)(yb * (int)p.Wd * 4), 0);
+  };
+  // unprocessed border rows of this strip are written 0
+  for (int y = y0; y < min(vy0, y1); ++y) store_row(y, 0u);
+  for (int y = max(vy1, y0); y < y1; ++y) store_row(y, 0u);
+  if (vy0 >= vy1) {
+    for (int yb = y0 >> 3; yb * 8 < y1; ++yb) store_cand(yb, 0u);
+    return;
+  }
+
+  RowT T0, T1, T2;
+  make_row(load_row(vy0 - 1), T0);
+  make_row(load_row(vy0), T1);
+  // rows up to y+7 are prefetched (clamped to the frame)
+  uint32_t pf0 = load_row(vy0 + 1), pf1 = load_row(min(vy0 + 2, H - 1)), pf2 = load_row(min(vy0 + 3, H - 1)),
+           pf3 = load_row(min(vy0 + 4, H - 1)), pf4 = load_row(min(vy0 + 5, H - 1)),
+           pf5 = load_row(min(vy0 + 6, H - 1));
+
+  uint32_t C = 0;
+  // one output row: consume the prefetched row y+1, refill the prefetch slot with row y+7
+#define RMX_STEP(A, B, Cn, PF, R)                                                        \
+  {                                                                                      \
+    const int yy = y + R;                                                                \
+    make_row(PF, Cn);                                                                    \
+    PF = load_row(min(yy + 7, H - 1));                                                   \
+    uint32_t pk = merge_rows(A, B, Cn);                                                  \
+    store_row(yy, pk & maskx);                                                           \
+    uint32_t t = ((((pk ^ B.key) & maskx) + 0x0f0f0f0fu) & 0x10101010u);                 \
+    const uint32_t r = (uint32_t)yy & 7u;                                                \
+    C |= r < 4 ? t << r : (t >> 4) << (r - 4);                                           \
+    if (r == 7u) {                                                                       \
+      store_cand(yy >> 3, C);                                                            \
+      C = 0;                                                                             \
+    }                                                                                    \
+  }
+  int y = vy0;
+  for (; y + 6 <= vy1; y += 6) {  // steady state: six rows, no per-row conditions on validity
+    RMX_STEP(T0, T1, T2, pf0, 0)
+    RMX_STEP(T1, T2, T0, pf1, 1)
+    RMX_STEP(T2, T0, T1, pf2, 2)
+    RMX_STEP(T0, T1, T2, pf3, 3)
+    RMX_STEP(T1, T2, T0, pf4, 4)
+    RMX_STEP(T2, T0, T1, pf5, 5)
+  }
+  if (y < vy1) RMX_STEP(T0, T1, T2, pf0, 0)
+  if (y + 1 < vy1) RMX_STEP(T1, T2, T0, pf1, 1)
+  if (y + 2 < vy1) RMX_STEP(T2, T0, T1, pf2, 2)
+  if (y + 3 < vy1) RMX_STEP(T0, T1, T2, pf3, 3)
+  if (y + 4 < vy1) RMX_STEP(T1, T2, T0, pf4, 4)
+#undef RMX_STEP
+  // last (partial) block of the strip and blocks that hold only border rows
+  if ((vy1 & 7) != 0) store_cand(vy1 >> 3, C);
+  for (int yb = (vy1 + 7) >> 3; yb * 8 < y1; ++yb) store_cand(yb, 0u);
+}
+
+// ---- kernel 2: finish the candidates ---------------------------------------------------------------
+// compute_pixel's second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379) for one
+// candidate pixel per lane: gather the 5x5 window (L1/L2-resident: kpe_main just streamed
+// it), 12th largest of 25 by a 4-step binary search on the rank with SWAR byte compares
+// counted by v_sad_u8, weight, code bytes, append.
+__device__ __forceinline__ void finish_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool active) {
   if (!active) {
     x = 2;
     y = 2;
     f = 0;
   }
-  const uint8_t* base = p.frames + (size_t)f * p.W * p.H + (size_t)(y - 2) * p.W + ((x - 2) & ~3u);
+  const size_t fo = (size_t)f * p.W * p.H;
+  const uint8_t* base = p.frames + fo + (size_t)(y - 2) * p.W + ((x - 2) & ~3u);
   const uint32_t s = (x - 2) & 3u;
   uint32_t w[5], e[5];
 #pragma unroll
@@ -123,12 +247,15 @@ __device__ __forceinline__ void finish_candidates(const KpeParams& p, uint32_t e
     w[r] = __builtin_amdgcn_alignbyte(hi, lo, s);  // pixels x-2 .. x+1
     e[r] = (hi >> (8 * s)) & 0xffu;                // pixel  x+2
   }
+  // p3 = rank of the median kpe_main stored for this pixel (kpe.hpp:313-314)
+  const uint32_t mnat = p.median[fo + (size_t)y * p.W + x] & 0xfu;
   uint32_t v[7];
 #pragma unroll
   for (int r = 0; r < 5; ++r) v[r] = map_ord(w[r]) | 0x80808080u;
   v[5] = map_ord(e[0] | e[1] << 8 | e[2] << 16 | e[3] << 24) | 0x80808080u;
   v[6] = map_ord(e[4]) | 0x80808080u;  // unused bytes hold rank 0: never >= a threshold >= 1
   const uint32_t p1 = (v[2] >> 16) & 0xfu;
+  const uint32_t p3r = map_ord(mnat) & 0xfu;
   // largest t with #(rank >= t) >= 12  ==  first bin from the top whose running total
   // reaches 12 (kpe.hpp:326-340)
   uint32_t t = 0;
@@ -142,7 +269,7 @@ __device__ __forceinline__ void finish_candidates(const KpeParams& p, uint32_t e
     if ((acc >> 7) >= 12u) t = c;
   }
   const uint32_t p5 = t;
-  const bool kp = active && (p3 != p5);
+  const bool kp = active && (p3r != p5);
   if (__builtin_amdgcn_ballot_w64(kp) == 0) return;
   const uint32_t weight = (p1 != p5) ? 2u : 1u;
   // code bytes (kpe.hpp:342-379): see oracle/remap_oracle.cpp encode_ref for the derivation
@@ -168,103 +295,74 @@ __device__ __forceinline__ void finish_candidates(const KpeParams& p, uint32_t e
   }
 }
 
-__global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
-  __shared__ uint32_t q_xy[4][QCAP];
-  __shared__ uint32_t q_f[4][QCAP];
-  const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-
-  // XCD-aware block remap (bijective): blocks that share an XCD get neighbouring groups.
-  const uint32_t nb = gridDim.x, bid = blockIdx.x;
-  const uint32_t bq = nb >> 3, br = nb & 7u, xcd = bid & 7u;
-  const uint32_t lb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (bid >> 3);
-  const uint32_t g = lb * 4 + wv;
-  if (g >= p.groups) return;  // whole wave; no block-level barriers are used below
-
-  const int64_t L = (int64_t)g * 62 - 1 + (int64_t)lane;
-  const bool lane_ok = lane >= 1 && lane <= 62 && L >= 0 && L < (int64_t)p.V;
-  const uint64_t Lc = L < 0 ? 0 : (L >= (int64_t)p.V ? p.V - 1 : (uint64_t)L);
-  const uint32_t f = (uint32_t)(Lc / p.Wd), c = (uint32_t)(Lc % p.Wd);
-  const size_t fbase = (size_t)f * p.W * p.H + (size_t)c * 4;
-  const uint8_t* src = p.frames + fbase;
-  uint8_t* dst = p.median + fbase;
-
-  // per-pixel x validity: processed x in [2, W-3] (kpe.hpp:183-184)
-  uint32_t maskx = 0;
+// One workgroup per (frame, chunk of 256 candidate words): count, scan, then hand the set
+// bits out densely, 256 candidates at a time.
+__global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
+  __shared__ uint32_t s_base[257];
+  __shared__ uint32_t s_word[256];
+  __shared__ uint32_t s_yc[256];
+  __shared__ uint32_t s_scan[8];
+  const uint32_t tid = threadIdx.x;
+  const uint32_t wpf = p.HB * p.Wd;            // words per frame
+  const uint32_t cpf = (wpf + 255) / 256;      // chunks per frame
+  const uint32_t f = blockIdx.x / cpf, chunk = blockIdx.x - f * cpf;
+  const uint32_t wi = chunk * 256 + tid;
+  uint32_t word = 0;
+  if (wi < wpf) word = p.cand[(size_t)f * wpf + wi];
+  uint32_t cnt = (uint32_t)__builtin_popcount(word);
+  // block exclusive scan of cnt
+  const uint32_t lane = tid & 63u, wv = tid >> 6;
+  uint32_t incl = cnt;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    uint32_t x = c * 4 + j;
-    if (x >= 2 && x + 3 <= p.W) maskx |= 0x0fu << (8 * j);
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
   }
-  if (!lane_ok) maskx = 0;
-
-  const int H = (int)p.H, W = (int)p.W;
-  const int y0 = (int)(blockIdx.y * p.rows_per_strip);
-  const int y1 = min(H, y0 + (int)p.rows_per_strip);
-  auto load_row = [&](int y) -> uint32_t {
-    int yy = y < 0 ? 0 : (y > H - 1 ? H - 1 : y);
-    return *reinterpret_cast<const uint32_t*>(src + (size_t)yy * W);
-  };
-
-  RowT T0, T1, T2;
-  make_row(load_row(y0 - 1), T0);
-  make_row(load_row(y0), T1);
-  uint32_t pf0 = load_row(y0 + 1), pf1 = load_row(y0 + 2), pf2 = load_row(y0 + 3);
-
-  uint32_t qlen = 0;  // wave-uniform
-  uint32_t* qxy = q_xy[wv];
-  uint32_t* qf = q_f[wv];
-
-  auto drain = [&](bool all) {
-    while (qlen >= 64u || (all && qlen > 0u)) {
-      uint32_t take = qlen >= 64u ? 64u : qlen;
-      uint32_t idx = qlen - take + lane;
-      bool active = lane < take;
-      uint32_t exy = active ? qxy[idx] : 0u;
-      uint32_t ef = active ? qf[idx] : 0u;
-      qlen -= take;
-      finish_candidates(p, exy, ef, active);
-    }
-  };
-
-  for (int y = y0; y < y1; y += 3) {
-    uint32_t C = 0, pk0 = 0, pk1 = 0, pk2 = 0;
-#define RMX_STEP(A, B, Cn, PF, PK, R)                                               \
-  if (y + R < y1) {                                                                 \
-    make_row(PF, Cn);                                                               \
-    PF = load_row(y + R + 4);                                                       \
-    const int yy = y + R;                                                           \
-    uint32_t med = 0;                                                               \
-    if (yy >= 2 && yy + 5 <= H) {                                                   \
-      PK = merge_rows(A, B, Cn);                                                    \
-      med = PK & maskx;                                                             \
-      uint32_t diff = (PK ^ B.key) & maskx;                                         \
-      C |= ((diff + 0x0f0f0f0fu) & 0x10101010u) << R;                               \
-    }                                                                               \
-    if (lane_ok) *reinterpret_cast<uint32_t*>(dst + (size_t)yy * W) = med;          \
+  if (lane == 63) s_scan[wv] = incl;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+  for (uint32_t k = 0; k < 4; ++k) {
+    uint32_t sc = s_scan[k];
+    if (k < wv) wbase += sc;
+    total += sc;
   }
-    RMX_STEP(T0, T1, T2, pf0, pk0, 0)
-    RMX_STEP(T1, T2, T0, pf1, pk1, 1)
-    RMX_STEP(T2, T0, T1, pf2, pk2, 2)
-#undef RMX_STEP
-    // compact this row triple's candidate pixels into the wave's queue
-    for (;;) {
-      uint64_t bal = __builtin_amdgcn_ballot_w64(C != 0u);
-      if (bal == 0) break;
-      if (C != 0u) {
-        uint32_t b = (uint32_t)__builtin_ctz(C);
-        C &= C - 1u;
-        uint32_t j = b >> 3, r = (b & 7u) - 4u;
-        uint32_t pk = r == 0 ? pk0 : (r == 1 ? pk1 : pk2);
-        uint32_t p3 = (pk >> (8 * j + 4)) & 0xfu;
-        uint32_t pos = qlen + mbcnt(bal);
-        qxy[pos] = (c * 4 + j) | (uint32_t)(y + (int)r) << 16;
-        qf[pos] = f | p3 << 28;
+  s_base[tid] = wbase + incl - cnt;
+  s_word[tid] = word;
+  {
+    uint32_t yb = wi / p.Wd;
+    s_yc[tid] = yb << 16 | (wi - yb * p.Wd);
+  }
+  if (tid == 0) s_base[256] = total;
+  __syncthreads();
+  for (uint32_t k0 = 0; k0 < total; k0 += 256) {
+    const uint32_t k = k0 + tid;
+    const bool active = k < total;
+    uint32_t x = 2, y = 2;
+    if (active) {
+      uint32_t lo = 0, hi = 256;  // largest t with s_base[t] <= k and s_word[t] != 0 following
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (s_base[mid] <= k)
+          lo = mid;
+        else
+          hi = mid;
       }
-      qlen += (uint32_t)__builtin_popcountll(bal);
-      drain(false);
+      uint32_t nth = k - s_base[lo], w = s_word[lo], b = 0;
+#pragma unroll
+      for (uint32_t sft = 16; sft >= 1; sft >>= 1) {
+        uint32_t lowc = (uint32_t)__builtin_popcount(w & ((1u << sft) - 1u));
+        if (nth >= lowc) {
+          nth -= lowc;
+          w >>= sft;
+          b += sft;
+        }
+      }
+      uint32_t yc = s_yc[lo];
+      x = (yc & 0xffffu) * 4 + (b >> 3);
+      y = (yc >> 16) * 8 + ((b & 7u) ^ 4u);
     }
+    finish_candidate(p, x, y, f, active);
   }
-  drain(true);
 }
 
 }  // namespace rmx

@@ -58,8 +58,9 @@ def build(force=False, verbose=False):
     """hipcc --offload-arch=gfx950 -> remap_amd/libremap_amd.so (cross-compiles without a GPU)."""
     if not force and not needs_build():
         return SO_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC",
-           os.path.join(SRC_DIR, "api.hip"), "-o", SO_PATH]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC"]
+    cmd += os.environ.get("RMX_CFLAGS", "").split()  # experiment switches (tools/), never set by tests/bench
+    cmd += [os.path.join(SRC_DIR, "api.hip"), "-o", SO_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

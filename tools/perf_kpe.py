@@ -13,11 +13,11 @@ med = torch.empty_like(d); desc,kc = ctx.alloc_tables(n)
 ctx.kpe(d, med, desc, kc); ctx.sync()
 ctx.set_timing(True)
 for it in range(3):
-    ctx.kpe(d, med, desc, kc)
+    ctx.set_timing(True); ctx.kpe(d, med, desc, kc)
     K = int(kc.sum().item())
-    ms = ctx.kernel_ms("kpe_main"); mt = ctx.kernel_ms("kpe_table")
+    ms = ctx.kernel_ms("kpe_main"); mt = ctx.kernel_ms("kpe_table"); mf = ctx.kernel_ms("kpe_finish")
     byts = 2*W*H*n + 18*K
-    print(f"n={n} dens={dens} K/frame={K/n:.1f} kpe_main {ms:.3f} ms -> {byts/ms/1e9*1e3/1e3:.3f} TB/s alg ({n/ms*1e3:.0f} fps) ; table {mt:.3f} ms")
+    print(f"n={n} dens={dens} K/frame={K/n:.1f} kpe_main {ms:.3f} ms -> {byts/ms/1e9*1e3/1e3:.3f} TB/s alg ({n/ms*1e3:.0f} fps) ; finish {mf:.3f} table {mt:.3f} ms")
 ctx.set_timing(False)
 torch.cuda.synchronize(); t=time.time()
 for it in range(5): ctx.kpe(d, med, desc, kc)
