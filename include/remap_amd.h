@@ -195,10 +195,13 @@ void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
 /* Kernel timing with HIP events recorded on the context stream around each launch (no host
  * synchronisation while recording).  rmx_set_timing(ctx, 1) opens a measurement window (and
  * drops earlier samples); rmx_last_kernel_ms synchronises the stream and returns the AVERAGE
- * duration in milliseconds of `kernel` ("kpe_main", "kpe_table", "kpm_build", "kpm_match",
+ * duration in milliseconds of `kernel` ("kpe_main", "kpe_finish", "kpe_table", "kpm_build", "kpm_match",
  * "fgm_blit") over the launches of the window (0 if none). */
 int rmx_set_timing(rmx_ctx* ctx, int enabled);
 int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms);
+/* Number of launches of `kernel` recorded in the current window (rmx_kpe_batch walks a big
+ * batch in cache-sized sub-batches, one kpe_main + kpe_finish launch each). */
+int rmx_kernel_launches(rmx_ctx* ctx, const char* kernel, uint32_t* launches);
 
 #ifdef __cplusplus
 }

@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -28,6 +29,7 @@ struct rmx_ctx {
   uint32_t* kraw = nullptr;
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t n_cap = 0;
+  uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   KpmWorkspace kpm{};
   size_t ws_bytes = 0;
@@ -159,6 +161,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   ctx->overlap = overlap;
   ctx->kmax = kmax;
   ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
+  if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess) {
     delete ctx;
@@ -200,7 +203,15 @@ int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   return RMX_OK;
 }
 
-int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) {
+static int kernel_stats(rmx_ctx* ctx, const char* kernel, float* ms, uint32_t* launches);
+
+int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) { return kernel_stats(ctx, kernel, ms, nullptr); }
+int rmx_kernel_launches(rmx_ctx* ctx, const char* kernel, uint32_t* launches) {
+  float ms;
+  return kernel_stats(ctx, kernel, &ms, launches);
+}
+
+static int kernel_stats(rmx_ctx* ctx, const char* kernel, float* ms, uint32_t* launches) {
   if (!ctx || !kernel || !ms) return RMX_ERR_ARG;
   std::string k(kernel);
   rmx_ctx::Track* t = nullptr;
@@ -226,6 +237,7 @@ int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms) {
     sum += v;
   }
   *ms = t->used ? (float)(sum / (double)t->used) : 0.f;
+  if (launches) *launches = (uint32_t)t->used;
   return RMX_OK;
 }
 
@@ -235,38 +247,47 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   RMX_HIP(hipSetDevice(ctx->device));
   if (int rc = ensure_workspace(ctx, n)) return rc;
   RMX_HIP(hipMemsetAsync(ctx->kraw, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
-  KpeParams p{};
-  p.frames = frames;
-  p.median = median;
-  p.raw = ctx->raw;
-  p.kcount = ctx->kraw;
-  p.status = ctx->status;
-  p.n = n;
-  p.W = ctx->W;
-  p.H = ctx->H;
-  p.Wd = ctx->W / 4;
-  p.V = (uint64_t)n * p.Wd;
-  p.groups = (uint32_t)((p.V + 61) / 62);
-  // strips (multiples of 8 rows): enough waves to fill the chip for small batches, long
-  // strips (less halo-row re-reading) for big ones
-  uint32_t rps = 48;
-  while (rps > 8 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 8;
-  p.rows_per_strip = rps;
-  p.kmax = ctx->kmax;
-  p.cand = ctx->cand;
-  p.HB = (ctx->H + 7) / 8;
-  dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
-  {
-    Timer t(ctx, &ctx->ms_kpe);
-    hipLaunchKernelGGL(kpe_main, grid, dim3(256), 0, ctx->stream, p);
+  // Optional sub-batching (RMX_SUB_MIB): keeping frames + medians + candidate plane inside
+  // the 256 MiB Infinity Cache between the streaming and the finishing pass was measured
+  // SLOWER at every size (small launches cost more than the re-reads), so the default is
+  // one launch pair for the whole batch.
+  const size_t per_frame = (size_t)ctx->W * ctx->H * 2 + (size_t)((ctx->H + 7) / 8) * (ctx->W / 4) * 4;
+  uint32_t sub = (uint32_t)std::max<size_t>(1, ((size_t)ctx->sub_mib << 20) / per_frame);
+  for (uint32_t f0 = 0; f0 < n; f0 += sub) {
+    const uint32_t m = std::min(sub, n - f0);
+    KpeParams p{};
+    p.frames = frames + (size_t)f0 * ctx->W * ctx->H;
+    p.median = median + (size_t)f0 * ctx->W * ctx->H;
+    p.raw = ctx->raw + (size_t)f0 * ctx->kmax;
+    p.kcount = ctx->kraw + f0;
+    p.status = ctx->status;
+    p.n = m;
+    p.W = ctx->W;
+    p.H = ctx->H;
+    p.Wd = ctx->W / 4;
+    p.V = (uint64_t)m * p.Wd;
+    p.groups = (uint32_t)((p.V + 61) / 62);
+    // strips (multiples of 8 rows): enough waves to fill the chip for small batches, long
+    // strips (less halo-row re-reading) for big ones
+    uint32_t rps = 48;
+    while (rps > 8 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 8;
+    p.rows_per_strip = rps;
+    p.kmax = ctx->kmax;
+    p.HB = (ctx->H + 7) / 8;
+    p.cand = ctx->cand + (size_t)f0 * p.HB * p.Wd;
+    dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
+    {
+      Timer t(ctx, &ctx->ms_kpe);
+      hipLaunchKernelGGL(kpe_main, grid, dim3(256), 0, ctx->stream, p);
+    }
+    RMX_HIP(hipGetLastError());
+    {
+      Timer t(ctx, &ctx->ms_finish);
+      const uint32_t cpf = (p.HB * p.Wd + FIN_WORDS - 1) / FIN_WORDS;
+      hipLaunchKernelGGL(kpe_finish, dim3(m * cpf), dim3(256), 0, ctx->stream, p);
+    }
+    RMX_HIP(hipGetLastError());
   }
-  RMX_HIP(hipGetLastError());
-  {
-    Timer t(ctx, &ctx->ms_finish);
-    const uint32_t cpf = (p.HB * p.Wd + 255) / 256;
-    hipLaunchKernelGGL(kpe_finish, dim3(n * cpf), dim3(256), 0, ctx->stream, p);
-  }
-  RMX_HIP(hipGetLastError());
   TableParams tp{};
   tp.raw = ctx->raw;
   tp.kcount = ctx->kraw;

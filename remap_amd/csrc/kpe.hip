@@ -226,36 +226,46 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
 }
 
 // ---- kernel 2: finish the candidates ---------------------------------------------------------------
-// compute_pixel's second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379) for one
-// candidate pixel per lane: gather the 5x5 window (L1/L2-resident: kpe_main just streamed
-// it), 12th largest of 25 by a 4-step binary search on the rank with SWAR byte compares
-// counted by v_sad_u8, weight, code bytes, append.
-__device__ __forceinline__ void finish_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool active) {
-  if (!active) {
-    x = 2;
-    y = 2;
-    f = 0;
-  }
+// compute_pixel's second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379).
+// A candidate's data moves in two phases so that several candidates per lane can be in
+// flight: gather (11 loads from L2 / Infinity Cache: kpe_main just streamed these lines)
+// and resolve (rank 12 of 25 by a 4-step binary search with SWAR byte compares counted by
+// v_sad_u8, weight, code bytes, append).
+struct CandData {
+  uint32_t lo[5], hi[5];
+  uint32_t med;
+};
+
+__device__ __forceinline__ void gather_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, CandData& d) {
   const size_t fo = (size_t)f * p.W * p.H;
   const uint8_t* base = p.frames + fo + (size_t)(y - 2) * p.W + ((x - 2) & ~3u);
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)r * p.W);  // 4-byte aligned dwordx2
+    d.lo[r] = v.x;
+    d.hi[r] = v.y;
+  }
+  d.med = p.median[fo + (size_t)y * p.W + x];
+}
+
+__device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool active,
+                                                  const CandData& d) {
   const uint32_t s = (x - 2) & 3u;
   uint32_t w[5], e[5];
 #pragma unroll
   for (int r = 0; r < 5; ++r) {
-    uint32_t lo = *reinterpret_cast<const uint32_t*>(base + (size_t)r * p.W) & 0x0f0f0f0fu;
-    uint32_t hi = *reinterpret_cast<const uint32_t*>(base + (size_t)r * p.W + 4) & 0x0f0f0f0fu;
+    uint32_t lo = d.lo[r] & 0x0f0f0f0fu, hi = d.hi[r] & 0x0f0f0f0fu;
     w[r] = __builtin_amdgcn_alignbyte(hi, lo, s);  // pixels x-2 .. x+1
     e[r] = (hi >> (8 * s)) & 0xffu;                // pixel  x+2
   }
-  // p3 = rank of the median kpe_main stored for this pixel (kpe.hpp:313-314)
-  const uint32_t mnat = p.median[fo + (size_t)y * p.W + x] & 0xfu;
   uint32_t v[7];
 #pragma unroll
   for (int r = 0; r < 5; ++r) v[r] = map_ord(w[r]) | 0x80808080u;
   v[5] = map_ord(e[0] | e[1] << 8 | e[2] << 16 | e[3] << 24) | 0x80808080u;
   v[6] = map_ord(e[4]) | 0x80808080u;  // unused bytes hold rank 0: never >= a threshold >= 1
   const uint32_t p1 = (v[2] >> 16) & 0xfu;
-  const uint32_t p3r = map_ord(mnat) & 0xfu;
+  // p3 = rank of the median kpe_main stored for this pixel (kpe.hpp:313-314)
+  const uint32_t p3 = map_ord(d.med & 0xfu) & 0xfu;
   // largest t with #(rank >= t) >= 12  ==  first bin from the top whose running total
   // reaches 12 (kpe.hpp:326-340)
   uint32_t t = 0;
@@ -269,7 +279,7 @@ __device__ __forceinline__ void finish_candidate(const KpeParams& p, uint32_t x,
     if ((acc >> 7) >= 12u) t = c;
   }
   const uint32_t p5 = t;
-  const bool kp = active && (p3r != p5);
+  const bool kp = active && (p3 != p5);
   if (__builtin_amdgcn_ballot_w64(kp) == 0) return;
   const uint32_t weight = (p1 != p5) ? 2u : 1u;
   // code bytes (kpe.hpp:342-379): see oracle/remap_oracle.cpp encode_ref for the derivation
@@ -284,33 +294,39 @@ __device__ __forceinline__ void finish_candidate(const KpeParams& p, uint32_t x,
   if (kp) {
     uint32_t slot = atomicAdd(&p.kcount[f], 1u);
     if (slot < p.kmax) {
-      RawDesc* d = p.raw + (size_t)f * p.kmax + slot;
+      RawDesc* dd = p.raw + (size_t)f * p.kmax + slot;
       uint4 c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);
       uint4 m4 = make_uint4(x | y << 16, 0u, 0u, 0u);
-      reinterpret_cast<uint4*>(d)[0] = c4;
-      reinterpret_cast<uint4*>(d)[1] = m4;
+      reinterpret_cast<uint4*>(dd)[0] = c4;
+      reinterpret_cast<uint4*>(dd)[1] = m4;
     } else {
       atomicOr(&p.status[0], 1u);
     }
   }
 }
 
-// One workgroup per (frame, chunk of 256 candidate words): count, scan, then hand the set
-// bits out densely, 256 candidates at a time.
+constexpr uint32_t FIN_WORDS = 4096;  // candidate words per workgroup (16 per thread)
+
+// One workgroup per (frame, chunk of FIN_WORDS candidate words): every thread owns 16
+// consecutive words, the set bits are numbered by a block scan and handed out densely, two
+// candidates per thread per pass with both gathers issued before either is resolved.
 __global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
-  __shared__ uint32_t s_base[257];
-  __shared__ uint32_t s_word[256];
-  __shared__ uint32_t s_yc[256];
+  __shared__ uint32_t s_word[FIN_WORDS];
+  __shared__ uint32_t s_tbase[257];
   __shared__ uint32_t s_scan[8];
   const uint32_t tid = threadIdx.x;
-  const uint32_t wpf = p.HB * p.Wd;            // words per frame
-  const uint32_t cpf = (wpf + 255) / 256;      // chunks per frame
+  const uint32_t wpf = p.HB * p.Wd;                       // words per frame
+  const uint32_t cpf = (wpf + FIN_WORDS - 1) / FIN_WORDS;  // chunks per frame
   const uint32_t f = blockIdx.x / cpf, chunk = blockIdx.x - f * cpf;
-  const uint32_t wi = chunk * 256 + tid;
-  uint32_t word = 0;
-  if (wi < wpf) word = p.cand[(size_t)f * wpf + wi];
-  uint32_t cnt = (uint32_t)__builtin_popcount(word);
-  // block exclusive scan of cnt
+  const uint32_t w0 = chunk * FIN_WORDS;
+  const uint32_t nw = min(FIN_WORDS, wpf - w0);
+  const uint32_t* src = p.cand + (size_t)f * wpf + w0;
+  // coalesced load into LDS, then per-thread counts over 16 consecutive words
+  for (uint32_t i = tid; i < FIN_WORDS; i += 256) s_word[i] = i < nw ? src[i] : 0u;
+  __syncthreads();
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t i = 0; i < 16; ++i) cnt += (uint32_t)__builtin_popcount(s_word[tid * 16 + i]);
   const uint32_t lane = tid & 63u, wv = tid >> 6;
   uint32_t incl = cnt;
 #pragma unroll
@@ -326,42 +342,52 @@ __global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
     if (k < wv) wbase += sc;
     total += sc;
   }
-  s_base[tid] = wbase + incl - cnt;
-  s_word[tid] = word;
-  {
-    uint32_t yb = wi / p.Wd;
-    s_yc[tid] = yb << 16 | (wi - yb * p.Wd);
-  }
-  if (tid == 0) s_base[256] = total;
+  s_tbase[tid] = wbase + incl - cnt;
+  if (tid == 0) s_tbase[256] = total;
   __syncthreads();
-  for (uint32_t k0 = 0; k0 < total; k0 += 256) {
-    const uint32_t k = k0 + tid;
-    const bool active = k < total;
-    uint32_t x = 2, y = 2;
-    if (active) {
-      uint32_t lo = 0, hi = 256;  // largest t with s_base[t] <= k and s_word[t] != 0 following
-      while (hi - lo > 1) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (s_base[mid] <= k)
-          lo = mid;
-        else
-          hi = mid;
-      }
-      uint32_t nth = k - s_base[lo], w = s_word[lo], b = 0;
-#pragma unroll
-      for (uint32_t sft = 16; sft >= 1; sft >>= 1) {
-        uint32_t lowc = (uint32_t)__builtin_popcount(w & ((1u << sft) - 1u));
-        if (nth >= lowc) {
-          nth -= lowc;
-          w >>= sft;
-          b += sft;
-        }
-      }
-      uint32_t yc = s_yc[lo];
-      x = (yc & 0xffffu) * 4 + (b >> 3);
-      y = (yc >> 16) * 8 + ((b & 7u) ^ 4u);
+
+  auto locate = [&](uint32_t k, uint32_t& x, uint32_t& y) {
+    uint32_t lo = 0, hi = 256;  // owner thread: largest t with s_tbase[t] <= k
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (s_tbase[mid] <= k)
+        lo = mid;
+      else
+        hi = mid;
     }
-    finish_candidate(p, x, y, f, active);
+    uint32_t nth = k - s_tbase[lo], wi = lo * 16, w = s_word[wi];
+    for (;;) {  // walk the owner's words
+      uint32_t c = (uint32_t)__builtin_popcount(w);
+      if (nth < c) break;
+      nth -= c;
+      w = s_word[++wi];
+    }
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t sft = 16; sft >= 1; sft >>= 1) {
+      uint32_t lowc = (uint32_t)__builtin_popcount(w & ((1u << sft) - 1u));
+      if (nth >= lowc) {
+        nth -= lowc;
+        w >>= sft;
+        b += sft;
+      }
+    }
+    const uint32_t gw = w0 + wi, yb = gw / p.Wd, c = gw - yb * p.Wd;
+    x = c * 4 + (b >> 3);
+    y = yb * 8 + ((b & 7u) ^ 4u);
+  };
+
+  for (uint32_t k0 = 0; k0 < total; k0 += 512) {
+    const uint32_t ka = k0 + tid, kb = k0 + 256 + tid;
+    const bool act_a = ka < total, act_b = kb < total;
+    uint32_t xa = 2, ya = 2, xb = 2, yb = 2;
+    if (act_a) locate(ka, xa, ya);
+    if (act_b) locate(kb, xb, yb);
+    CandData da, db;
+    gather_candidate(p, xa, ya, act_a ? f : 0u, da);
+    gather_candidate(p, xb, yb, act_b ? f : 0u, db);
+    resolve_candidate(p, xa, ya, f, act_a, da);
+    if (k0 + 256 < total) resolve_candidate(p, xb, yb, f, act_b, db);
   }
 }
 

@@ -161,7 +161,8 @@ __device__ __forceinline__ bool same_code(const uint32_t a[4], const uint32_t b[
   return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3];
 }
 
-// Exclusive prefix sum of one value per thread over a 256-thread block (LDS scratch: 8 u32).
+// Exclusive prefix sum of one value per thread over an NT-thread block (LDS scratch: 8 u32).
+template <uint32_t NT>
 __device__ inline uint32_t block_exscan(uint32_t v, uint32_t* scratch, uint32_t* total) {
   const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
   uint32_t incl = v;
@@ -170,11 +171,15 @@ __device__ inline uint32_t block_exscan(uint32_t v, uint32_t* scratch, uint32_t*
     uint32_t t = (uint32_t)__shfl_up((int)incl, o);
     if (lane >= (uint32_t)o) incl += t;
   }
+  if (NT == 64) {
+    *total = (uint32_t)__shfl((int)incl, 63);
+    return incl - v;
+  }
   __syncthreads();
   if (lane == 63) scratch[wv] = incl;
   __syncthreads();
   uint32_t base = 0, tot = 0;
-  for (uint32_t w = 0; w < 4; ++w) {
+  for (uint32_t w = 0; w < NT / 64; ++w) {
     uint32_t s = scratch[w];
     if (w < wv) base += s;
     tot += s;
@@ -183,11 +188,12 @@ __device__ inline uint32_t block_exscan(uint32_t v, uint32_t* scratch, uint32_t*
   return base + incl - v;
 }
 
+template <uint32_t NT>
 __device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
   for (uint32_t k = 2; k <= n2; k <<= 1) {
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       __syncthreads();
-      for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
+      for (uint32_t i = threadIdx.x; i < n2; i += NT) {
         uint32_t ixj = i ^ j;
         if (ixj > i) {
           uint32_t x = a[i], y = a[ixj];
@@ -203,15 +209,19 @@ __device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
-  __shared__ uint16_t ent[KPM_KMAX];       // scan indices of the region's entries, scan order
-  __shared__ uint16_t slot_of[KPM_KMAX];   // hash slot of entry i
-  __shared__ uint16_t gid_of[KPM_KMAX];    // rank of a group's first entry -> group id
-  __shared__ uint32_t htl[2 * KPM_KMAX];   // slot -> smallest entry rank with that code
-  __shared__ uint32_t keys[KPM_KMAX];
-  __shared__ uint64_t hg[KPM_GPOOL];       // group hashes in insertion order, pooled over regions
-  __shared__ uint16_t nxt[KPM_GPOOL];
-  __shared__ uint16_t bkt[8][KPM_BUCKETS + 3];
+// Two instances share the batch: <256, 64> (one wave, 19 KB of LDS, many per CU) takes the
+// frames with at most 256 keypoints, <2048, 256> the rest; each exits at once on frames of
+// the other class.
+template <uint32_t KC, uint32_t NT, uint32_t GPOOL, uint32_t BUCKETS>
+__global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p) {
+  __shared__ uint16_t ent[KC];       // scan indices of the region's entries, scan order
+  __shared__ uint16_t slot_of[KC];   // hash slot of entry i
+  __shared__ uint16_t gid_of[KC];    // rank of a group's first entry -> group id
+  __shared__ uint32_t htl[2 * KC];   // slot -> smallest entry rank with that code
+  __shared__ uint32_t keys[KC];
+  __shared__ uint64_t hg[GPOOL];     // group hashes in insertion order, pooled over regions
+  __shared__ uint16_t nxt[GPOOL];
+  __shared__ uint16_t bkt[8][BUCKETS + 3];
   __shared__ uint32_t scan_scratch[8];
   __shared__ uint32_t gl_off[9];           // region offsets into hg/nxt
   __shared__ uint32_t gg_off[8];           // region offsets into the frame's group arrays
@@ -222,6 +232,7 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
+  if (KC == 256 ? k > 256 : k <= 256) return;  // the other instance's frame (uniform)
   uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
   uint32_t* hdr = pool;
   uint32_t* pts = pool + kpm_off_pts(p.kmax);
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
 
   uint32_t p_off = 0, g_off = 0, ht_off = 0, gl = 0;  // running pool offsets (uniform)
   if (tid == 0) gl_off[0] = 0;
-  const uint32_t seg = (k + 255) / 256;  // contiguous entries per thread
+  const uint32_t seg = (k + NT - 1) / NT;  // contiguous entries per thread
 
   for (uint32_t r = 0; r < p.nreg; ++r) {
     // 1. compact the region's entries, preserving scan order
@@ -241,20 +252,20 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
     const uint32_t i0 = tid * seg, i1 = min(k, i0 + seg);
     for (uint32_t i = i0; i < i1; ++i) cnt += (desc[i].region_mask >> r) & 1u;
     uint32_t e = 0;
-    uint32_t w = block_exscan(cnt, scan_scratch, &e);
+    uint32_t w = block_exscan<NT>(cnt, scan_scratch, &e);
     for (uint32_t i = i0; i < i1; ++i)
       if ((desc[i].region_mask >> r) & 1u) ent[w++] = (uint16_t)i;
     uint32_t slots = 16;
     while (slots < 2 * e) slots <<= 1;
     const uint32_t mask = slots - 1;
-    for (uint32_t s = tid; s < slots; s += 256) htl[s] = EMPTY;
+    for (uint32_t s = tid; s < slots; s += NT) htl[s] = EMPTY;
     if (tid == 0) {
       s_w2 = 0;
       s_w1 = 0;
     }
     __syncthreads();
     // 2. group by code: slot value = smallest entry rank holding that code
-    for (uint32_t i = tid; i < e; i += 256) {
+    for (uint32_t i = tid; i < e; i += NT) {
       uint32_t c[4];
       load_code(desc + ent[i], c);
       uint32_t wgt = c[3] & 0xfu;
@@ -278,16 +289,16 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
     // 3. order entries by (first occurrence of their code, scan order)
     uint32_t n2 = 1;
     while (n2 < e) n2 <<= 1;
-    for (uint32_t i = tid; i < n2; i += 256) keys[i] = i < e ? (htl[slot_of[i]] << 16 | i) : 0xffffffffu;
-    bitonic_sort_u32(keys, n2);
+    for (uint32_t i = tid; i < n2; i += NT) keys[i] = i < e ? (htl[slot_of[i]] << 16 | i) : 0xffffffffu;
+    bitonic_sort_u32<NT>(keys, n2);
     // 4. groups: ids in first-occurrence order; points, starts, first indices, hashes
-    const uint32_t eseg = (e + 255) / 256;
+    const uint32_t eseg = (e + NT - 1) / NT;
     const uint32_t j0 = tid * eseg, j1 = min(e, j0 + eseg);
     uint32_t starts = 0;
     for (uint32_t j = j0; j < j1; ++j) starts += (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16));
     uint32_t G = 0;
-    uint32_t gid = block_exscan(starts, scan_scratch, &G);
-    const bool fits = gl + G <= KPM_GPOOL && G <= 2048;
+    uint32_t gid = block_exscan<NT>(starts, scan_scratch, &G);
+    const bool fits = gl + G <= GPOOL && G <= KC;
     for (uint32_t j = j0; j < j1; ++j) {
       uint32_t first = keys[j] >> 16, i = keys[j] & 0xffffu;
       const rmx_desc* d = desc + ent[i];
@@ -306,7 +317,7 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
     }
     __syncthreads();
     // 5. export the code index: slot -> group id + 1
-    for (uint32_t s = tid; s < slots; s += 256) {
+    for (uint32_t s = tid; s < slots; s += NT) {
       uint32_t v = htl[s];
       ght[ht_off + s] = v == EMPTY ? 0u : (uint32_t)gid_of[v] + 1u;
     }
@@ -341,9 +352,7 @@ __global__ __launch_bounds__(256) void kpm_build(KpmBuildParams p) {
 }
 
 // ---- matching --------------------------------------------------------------------------------------
-constexpr uint32_t KM_HSLOTS = 2048;   // offset hash slots per wave
-constexpr uint32_t KM_DMAX = 1024;     // distinct offsets per (pair, region)
-constexpr uint32_t KM_MG = 1024;       // matched code groups per (pair, region)
+constexpr uint32_t KM_NEEDS_LARGE = 0xffffffffu;  // ticket[0] marker left by the small instance
 
 struct KpmMatchParams {
   const rmx_desc* desc;
@@ -371,16 +380,25 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 
 // One wave per (pair, region).  Pair index q: current frame = q (q = 0 pairs the halo with
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
+// Two instances: SMALL (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
+// LDS, ~20 waves per CU) runs first on every (pair, region) and leaves the marker
+// KM_NEEDS_LARGE in the ticket when a limit is hit; the LARGE instance (2048 / 1024 / 1024)
+// then redoes exactly those.
+template <bool SMALL, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
   __shared__ uint32_t mg_p[KM_MG], mg_c[KM_MG], mg_base[KM_MG + 1];
   __shared__ uint64_t hh[KM_DMAX];
-  __shared__ uint16_t nxt[KM_DMAX], bkt[1109 + 3], pos_of[KM_DMAX];
+  __shared__ uint16_t nxt[KM_DMAX], bkt[KM_BK + 3], pos_of[KM_DMAX];
   __shared__ uint64_t skey[KM_DMAX];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t q = blockIdx.x / p.nreg, r = blockIdx.x % p.nreg;
   uint32_t* ticket = p.tickets + ((size_t)q * p.nreg + r) * 6;
+  if (!SMALL) {
+    if (ticket[0] != KM_NEEDS_LARGE) return;  // the small instance finished this one
+  }
+  __builtin_amdgcn_wave_barrier();
   if (lane < 6) ticket[lane] = 0;
   if (q == 0 && !p.has_halo) return;
   const uint32_t stride = kpm_stride_u32(p.kmax);
@@ -452,7 +470,12 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
     nm += cnt;
   }
   if (overflow) {
-    if (lane == 0) atomicOr(&p.status[1], 2u);
+    if (lane == 0) {
+      if (SMALL)
+        ticket[0] = KM_NEEDS_LARGE;
+      else
+        atomicOr(&p.status[1], 2u);
+    }
     return;
   }
   if (nm == 0) return;
@@ -483,7 +506,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
     int32_t dx = (int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu);
     int32_t dy = (int32_t)(pp >> 16) - (int32_t)(cp >> 16);
     uint32_t key = off_key(dx, dy);
-    uint32_t s = (key * 2654435761u) >> 21;  // 11 bits
+    uint32_t s = (key * 2654435761u) >> KM_HSHIFT;
     for (uint32_t probes = 0;; ++probes) {
       uint32_t v = atomicCAS(&hk[s], 0u, key);
       if (v == 0u) ++my_new;
@@ -500,7 +523,12 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) D += (uint32_t)__shfl_xor((int)D, o);
   if (D > KM_DMAX) {
-    if (lane == 0) atomicOr(&p.status[1], 4u);
+    if (lane == 0) {
+      if (SMALL)
+        ticket[0] = KM_NEEDS_LARGE;
+      else
+        atomicOr(&p.status[1], 4u);
+    }
     return;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");

@@ -31,7 +31,7 @@ SYMBOLS = [
     "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
-    "rmx_last_kernel_ms",
+    "rmx_last_kernel_ms", "rmx_kernel_launches",
 ]
 
 
@@ -107,6 +107,7 @@ def load():
     lib.rmx_luts.argtypes = [vp, vp]
     lib.rmx_set_timing.argtypes = [vp, C.c_int]
     lib.rmx_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
+    lib.rmx_kernel_launches.argtypes = [vp, C.c_char_p, C.POINTER(u32)]
     _lib = lib
     return lib
 
@@ -167,6 +168,11 @@ class Context:
     def kernel_ms(self, name):
         v = C.c_float()
         self._chk(self.lib.rmx_last_kernel_ms(self.h, name.encode(), C.byref(v)), "rmx_last_kernel_ms")
+        return v.value
+
+    def kernel_launches(self, name):
+        v = C.c_uint32()
+        self._chk(self.lib.rmx_kernel_launches(self.h, name.encode(), C.byref(v)), "rmx_kernel_launches")
         return v.value
 
     def workspace_bytes(self):

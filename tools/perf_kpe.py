@@ -15,9 +15,10 @@ ctx.set_timing(True)
 for it in range(3):
     ctx.set_timing(True); ctx.kpe(d, med, desc, kc)
     K = int(kc.sum().item())
-    ms = ctx.kernel_ms("kpe_main"); mt = ctx.kernel_ms("kpe_table"); mf = ctx.kernel_ms("kpe_finish")
+    nl = ctx.kernel_launches("kpe_main")
+    ms = ctx.kernel_ms("kpe_main") * nl; mt = ctx.kernel_ms("kpe_table"); mf = ctx.kernel_ms("kpe_finish") * nl
     byts = 2*W*H*n + 18*K
-    print(f"n={n} dens={dens} K/frame={K/n:.1f} kpe_main {ms:.3f} ms -> {byts/ms/1e9*1e3/1e3:.3f} TB/s alg ({n/ms*1e3:.0f} fps) ; finish {mf:.3f} table {mt:.3f} ms")
+    print(f"launches={nl} n={n} dens={dens} K/frame={K/n:.1f} kpe_main {ms:.3f} ms -> {byts/ms/1e9*1e3/1e3:.3f} TB/s alg ({n/ms*1e3:.0f} fps) ; finish {mf:.3f} table {mt:.3f} ms")
 ctx.set_timing(False)
 torch.cuda.synchronize(); t=time.time()
 for it in range(5): ctx.kpe(d, med, desc, kc)
