@@ -1,0 +1,3 @@
+// icd.hpp — forwards to the consolidated type header of the drop-in layer.
+#pragma once
+#include "../core.hpp"

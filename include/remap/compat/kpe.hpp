@@ -1,0 +1,3 @@
+// kpe.hpp — device-backed drop-in (see remap/collector.hpp).
+#pragma once
+#include "../collector.hpp"

@@ -79,6 +79,21 @@ const char* rmx_last_error(const rmx_ctx* ctx);
 /* Number of bytes of device workspace the context currently holds (diagnostics). */
 size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx);
 
+/* ---- device memory helpers -------------------------------------------------------------
+ * Thin wrappers so a host program (the C++ header layer under include/remap/, a cgo/JNI
+ * stub, ...) can stage buffers without linking the HIP runtime itself.  Uploads, memsets
+ * and device-to-device copies are asynchronous on the context stream; rmx_download
+ * synchronises. */
+int rmx_malloc(rmx_ctx* ctx, size_t bytes, void** out);
+int rmx_free(rmx_ctx* ctx, void* ptr);
+int rmx_upload(rmx_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
+int rmx_download(rmx_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
+int rmx_copy(rmx_ctx* ctx, void* dst_device, const void* src_device, size_t bytes);
+/* rows x width bytes from a pitched device array into a pitched host array; synchronises. */
+int rmx_download_2d(rmx_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch,
+                    size_t width, size_t rows);
+int rmx_memset(rmx_ctx* ctx, void* dst_device, int value, size_t bytes);
+
 /* ---- kpe: keypoint extraction --------------------------------------------------------- */
 
 /* Batched kpe::extractor::extract (kpe.hpp:92-108) over n frames stored back to back

@@ -241,6 +241,53 @@ static int kernel_stats(rmx_ctx* ctx, const char* kernel, float* ms, uint32_t* l
   return RMX_OK;
 }
 
+int rmx_malloc(rmx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out || bytes == 0) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMalloc(out, bytes));
+  return RMX_OK;
+}
+int rmx_free(rmx_ctx* ctx, void* ptr) {
+  if (!ctx) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ptr) RMX_HIP(hipFree(ptr));
+  return RMX_OK;
+}
+int rmx_upload(rmx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+  return RMX_OK;
+}
+int rmx_download(rmx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  return RMX_OK;
+}
+int rmx_download_2d(rmx_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width, size_t rows) {
+  if (!ctx || !dst || !src || width > dpitch || width > spitch) return RMX_ERR_ARG;
+  if (width == 0 || rows == 0) return RMX_OK;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, ctx->stream));
+  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  return RMX_OK;
+}
+int rmx_copy(rmx_ctx* ctx, void* dst, const void* src, size_t bytes) {
+  if (!ctx || !dst || !src) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+  return RMX_OK;
+}
+int rmx_memset(rmx_ctx* ctx, void* dst, int value, size_t bytes) {
+  if (!ctx || !dst) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipMemsetAsync(dst, value, bytes, ctx->stream));
+  return RMX_OK;
+}
+
 int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* median, rmx_desc* desc,
                   uint32_t* kcount) {
   if (!ctx || !frames || !median || !desc || !kcount || n == 0 || n > 0x0fffffffu) return RMX_ERR_ARG;

@@ -31,7 +31,8 @@ SYMBOLS = [
     "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
-    "rmx_last_kernel_ms", "rmx_kernel_launches",
+    "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
+    "rmx_memset",
 ]
 
 

@@ -1,0 +1,99 @@
+// drop_in.cpp — a caller written against the REFERENCE's header surface (frc.hpp, fgm.hpp,
+// kpe.hpp, kpm.hpp: same includes, type names and concepts as main.cpp uses), compiled
+// against the device-backed drop-in headers.  Prints what tests/test_dropin_gpu.py checks.
+//
+//   g++ -std=c++20 -O1 -Iinclude -Iinclude/remap/compat tests/cpp/drop_in.cpp -Lremap_amd -lremap_amd ...
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "frc.hpp"
+
+// same shape as main.cpp's file_feed (main.cpp:16-52), reading from one memory blob
+class mem_feed {
+public:
+  mem_feed(mrl::dimensions_t d, std::vector<std::uint8_t> const& blob) : dim_{d}, blob_{&blob} {}
+  bool has_more() const noexcept { return next_ * dim_.area() < blob_->size(); }
+  template <typename Alloc>
+  auto produce(Alloc const& alloc) {
+    using image_type = sid::nat::aimg_t<Alloc>;
+    image_type img{dim_, alloc};
+    std::memcpy(img.data(), blob_->data() + next_ * dim_.area(), dim_.area());
+    return ifd::frame<image_type>{next_++, std::move(img)};
+  }
+
+private:
+  mrl::dimensions_t dim_;
+  std::vector<std::uint8_t> const* blob_;
+  std::size_t next_{0};
+};
+
+struct noop_compression {
+  template <typename Alloc>
+  icd::compressed_t operator()(sid::nat::aimg_t<Alloc> const& img) const {
+    return icd::compressed_t(1, std::uint8_t(img.size() & 0xff));
+  }
+};
+
+// the constants of frc::collector::match_config (frc.hpp:30-44)
+struct seq_cfg {
+  using allocator_type = std::allocator<char>;
+  static constexpr std::size_t weight_switch{10};
+  static constexpr std::size_t region_votes{3};
+  allocator_type get_allocator() const noexcept { return {}; }
+};
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const std::size_t W = std::stoul(argv[2]), H = std::stoul(argv[3]);
+  std::ifstream in(argv[1], std::ios::binary);
+  std::vector<std::uint8_t> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  mrl::dimensions_t dim{W, H};
+
+  frc::collector collector{dim};
+  std::size_t calls = 0, entries = 0, last_no = 0;
+  bool ordered = true;
+  unsigned long long med_sum = 0;
+  auto cb = [&](fgm::fragment const& fragment, frc::frame_type const& frame, frc::image_type const& median,
+                frc::grid_type const& grid) {
+    ++calls;
+    ordered = ordered && frame.number_ == last_no + 1 && fragment.frames().back().number_ == frame.number_;
+    last_no = frame.number_;
+    for (auto& r : grid.regions()) entries += r.total_count();
+    for (auto const* p = median.data(); p < median.end(); ++p) med_sum += p->value;
+  };
+  collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+  auto fragments = collector.complete();
+
+  std::printf("calls %zu ordered %d entries %zu medsum %llu nfrag %zu\n", calls, int(ordered), entries, med_sum,
+              fragments.size());
+  std::size_t fi = 0;
+  for (auto& f : fragments) {
+    auto dots = f.dots();
+    unsigned long long s = 0;
+    for (auto const* d = dots.data(); d < dots.end(); ++d)
+      for (int b = 0; b < 16; ++b) s = s * 1000003ull + (*d)[b];
+    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu\n", fi, f.dimensions().width_,
+                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), s);
+    for (auto& fr : f.frames())
+      std::printf("frame %zu frag %zu pos %d %d packed %zu %zu\n", fr.number_, fi, fr.position_.x_, fr.position_.y_,
+                  fr.data_.image_.size(), fr.data_.median_.size());
+    ++fi;
+  }
+  // single-image kpe::extractor and pairwise kpm::match through the same surface
+  {
+    using grid_t = kpr::grid<4, 2, std::allocator<char>>;
+    kpe::extractor<grid_t, 16> ex{dim};
+    sid::nat::dimg_t a{dim}, b{dim}, ma{dim}, mb{dim};
+    std::memcpy(a.data(), blob.data(), dim.area());
+    std::memcpy(b.data(), blob.data() + dim.area(), dim.area());
+    auto ga = ex.extract(a, ma, std::allocator<char>{});
+    auto gb = ex.extract(b, mb, std::allocator<char>{});
+    auto off = kpm::match(seq_cfg{}, ga, gb);
+    std::size_t ea = 0;
+    for (auto& r : ga.regions()) ea += r.total_count();
+    std::printf("pair entries %zu matched %d off %d %d\n", ea, int(bool(off)), off ? off->x_ : 0, off ? off->y_ : 0);
+  }
+  return 0;
+}

@@ -1,0 +1,75 @@
+"""The C++ drop-in header surface (include/remap/*, reference names: frc::collector,
+kpe::extractor, kpm::match, fgm::fragment) driven by a caller written like main.cpp's,
+on the GPU, against the CPU oracle."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1
+from test_oracle_golden import poly_sum
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def build_driver(tmp):
+    L.load()
+    exe = os.path.join(tmp, "drop_in")
+    cmd = ["g++", "-std=c++20", "-O1", "-I" + os.path.join(ROOT, "include"),
+           "-I" + os.path.join(ROOT, "include", "remap", "compat"), os.path.join(ROOT, "tests", "cpp", "drop_in.cpp"),
+           "-L" + os.path.join(ROOT, "remap_amd"), "-lremap_amd", "-L/opt/rocm/lib", "-lamdhip64",
+           "-Wl,-rpath," + os.path.join(ROOT, "remap_amd"), "-Wl,-rpath,/opt/rocm/lib", "-o", exe]
+    subprocess.check_call(cmd)
+    return exe
+
+
+def test_collector_drop_in_matches_oracle(gpu, tmp_path):
+    exe = build_driver(str(tmp_path))
+    frames, truth = scroller_v1(100, dens=100)
+    frames = frames.copy()
+    frames[40] = 6  # a fragment break
+    blob = tmp_path / "frames.bin"
+    frames.tofile(blob)
+    out = subprocess.run([exe, str(blob), "320", "240"], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().splitlines()
+    head = dict(zip(lines[0].split()[::2], lines[0].split()[1::2]))
+    o = O.orc_frc(frames)
+    n = len(frames)
+    nfrag = int(o["frag"].max()) + 1
+    assert int(head["calls"]) == n - 1 and int(head["ordered"]) == 1 and int(head["nfrag"]) == nfrag
+    ent = 0
+    medsum = 0
+    for i in range(1, n):
+        med, desc, k = O.orc_kpe(frames[i])
+        ent += sum(bin(int(m)).count("1") for m in desc["region_mask"])
+        medsum += int(med.sum())
+    assert int(head["entries"]) == ent and int(head["medsum"]) == medsum
+    frag_lines = [l.split() for l in lines if l.startswith("fragment ")]
+    frame_lines = [l.split() for l in lines if l.startswith("frame ")]
+    assert len(frame_lines) == n
+    for f in range(nfrag):
+        sel = o["frag"] == f
+        cw, ch, zx, zy = O.orc_fgm_extent(o["pos"][sel], 320, 240)
+        fl = frag_lines[f]
+        assert [int(fl[3]), int(fl[4])] == [cw, ch] and [int(fl[6]), int(fl[7])] == [0, 0]
+        assert int(fl[9]) == int(sel.sum())
+        can = np.zeros((ch, cw, 16), np.uint16)
+        for i in np.nonzero(sel)[0]:
+            O.orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
+        assert int(fl[11]) == poly_sum(can)
+    for fl in frame_lines:
+        i, f = int(fl[1]), int(fl[3])
+        assert f == o["frag"][i]
+        sel = o["frag"] == f
+        _, _, zx, zy = O.orc_fgm_extent(o["pos"][sel], 320, 240)
+        assert [int(fl[5]), int(fl[6])] == (o["pos"][i] - [zx, zy]).tolist()
+        assert fl[8] == "1" and fl[9] == "1"  # the caller's compressor ran on image and median
+    pair = [l.split() for l in lines if l.startswith("pair ")][0]
+    m, d, _ = O.orc_kpm_grid(O.orc_kpe(frames[0])[1], O.orc_kpe(frames[1])[1])
+    d0 = O.orc_kpe(frames[0])[1]
+    assert int(pair[2]) == sum(bin(int(x)).count("1") for x in d0["region_mask"])
+    assert int(pair[4]) == m and (int(pair[6]), int(pair[7])) == d
