@@ -15,6 +15,7 @@
 #include "kpe.hip"
 #include "table.hip"
 #include "kpm.hip"
+#include "kpm_cell.hip"
 #include "fgm.hip"
 
 using namespace rmx;

@@ -226,6 +226,21 @@ class Context:
         self._chk(self.lib.rmx_kpm_tickets(self.h, n, out.ctypes.data), "rmx_kpm_tickets")
         return out
 
+    def kpm_cell_pairs(self, tables, kcounts, masks, dims, pairs, cell=(15, 15)):
+        """Cellular kpm::match for fragment pairs.  tables/masks: lists of CUDA tensors,
+        kcounts: list of ints, dims: [(w, h)], pairs: [(previous, current)].  Returns VOTE_DTYPE array."""
+        nf, npairs = len(tables), len(pairs)
+        tp = (C.c_void_p * nf)(*[t.data_ptr() for t in tables])
+        mp = (C.c_void_p * nf)(*[m.data_ptr() for m in masks])
+        kc = np.ascontiguousarray(kcounts, np.uint32)
+        dm = np.ascontiguousarray(dims, np.uint32).reshape(-1, 2)
+        pr = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        votes = np.zeros(npairs, VOTE_DTYPE)
+        if npairs:
+            self._chk(self.lib.rmx_kpm_cell_pairs(self.h, tp, kc.ctypes.data, mp, dm.ctypes.data, nf, pr.ctypes.data,
+                                                  npairs, cell[0], cell[1], votes.ctypes.data), "rmx_kpm_cell_pairs")
+        return votes
+
     def frc_scan(self, dxdy, matched, first_is_start=True, carry=None):
         t = self.torch
         n = dxdy.shape[0]

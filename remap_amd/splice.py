@@ -1,0 +1,128 @@
+"""Fragment splicing — the host side of fgs::splice (reference fgs.hpp:80-213) on top of the
+C ABI.  Everything that touches pixels or keypoints runs on the device:
+  extract_single  fgm blend (rmx_fgm_blend) + kpe with grid<1,1>, overlap 0 (rmx_kpe_batch)
+  match_*         cellular kpm::match for fragment pairs (rmx_kpm_cell_pairs)
+  splice_single   canvas growth + merge (rmx_fgm_merge)
+The greedy merge loop, its edge lists and their ORDER (select_match takes the first maximum,
+fgs.hpp:142-163) are inherently sequential and stay on the host, mirrored step by step.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import lib as L
+
+CELL = (15, 15)  # fgs.hpp:121
+SNIPPET_KMAX = 2048
+
+
+class Fragment:
+    """fgm::fragment with its canvas in HBM: (ch, cw, 16) int16 tensor, zero, step, frames."""
+
+    def __init__(self, canvas, zero, step, frames):
+        self.canvas, self.zero, self.step = canvas, (int(zero[0]), int(zero[1])), step
+        self.frames = [(int(n), (int(p[0]), int(p[1]))) for n, p in frames]
+
+    @property
+    def dims(self):
+        return self.canvas.shape[1], self.canvas.shape[0]
+
+    def normalize(self):  # fgm.hpp:137-143
+        zx, zy = self.zero
+        self.frames = [(n, (x - zx, y - zy)) for n, (x, y) in self.frames]
+        self.zero = (0, 0)
+
+    def _ensure(self, ctx, pos, dim):  # fgm.hpp:190-233
+        import torch
+
+        (zx, zy), (w, h), (sw, sh) = self.zero, self.dims, self.step
+        up = lambda c, s: (c + s - 1) // s * s
+        l = up(zx - pos[0], sw) if pos[0] < zx else 0
+        t = up(zy - pos[1], sh) if pos[1] < zy else 0
+        rx, ry = pos[0] + dim[0], pos[1] + dim[1]
+        r = up(rx - (zx + w), sw) if rx > 0 and rx > zx + w else 0
+        b = up(ry - (zy + h), sh) if ry > 0 and ry > zy + h else 0
+        if l or t or r or b:
+            big = torch.zeros((h + t + b, w + l + r, 16), dtype=torch.int16, device=self.canvas.device)
+            ctx.fgm_merge(big, self.canvas, (l, t))
+            self.canvas = big
+            self.zero = (zx - l, zy - t)
+
+    def blit_fragment(self, ctx, pos, other):  # fgm.hpp:99-113
+        self._ensure(ctx, pos, other.dims)
+        ctx.fgm_merge(self.canvas, other.canvas, (pos[0] - self.zero[0], pos[1] - self.zero[1]))
+        ox, oy = other.zero
+        self.frames += [(n, (x - ox + pos[0], y - oy + pos[1])) for n, (x, y) in other.frames]
+
+
+class _Snippet:
+    def __init__(self, fragment, mask, table, k):
+        self.fragment, self.mask, self.table, self.k = fragment, mask, table, k
+        self.edges = []  # [primary, (dx, dy), count, other snippet]
+
+
+def _extract_single(ctx_cache, frag, device):  # fgs.hpp:80-89
+    any_ctx = ctx_cache("any")
+    img, mask = any_ctx.fgm_blend(frag.canvas)
+    w, h = frag.dims
+    kctx = ctx_cache((w, h))
+    _, desc, kc = kctx.kpe(img[None].contiguous())
+    rc, maxk = kctx.kpe_status()
+    if rc:
+        raise L.RemapError(rc, "rmx_kpe_status", f"snippet has {maxk} keypoints > {SNIPPET_KMAX}")
+    return _Snippet(frag, mask, desc[0], int(kc[0].item()))
+
+
+def splice(fragments, device=0):
+    """fgs::splice over a list of normalised Fragments (collector.complete()).  Returns the
+    spliced fragments in the reference's list order."""
+    ctxs = {}
+
+    def ctx_cache(key):
+        if key not in ctxs:
+            w, h = (16, 8) if key == "any" else key
+            ctxs[key] = L.Context(w, h, grid=(1, 1), overlap=0, kmax=SNIPPET_KMAX, device=device)
+        return ctxs[key]
+
+    mctx = ctx_cache("any")
+    snippets = [_extract_single(ctx_cache, f, device) for f in fragments]  # extract_all, fgs.hpp:91-103
+
+    def match_partial(head, rest):  # fgs.hpp:119-133
+        if not rest:
+            return
+        group = [head] + rest
+        votes = mctx.kpm_cell_pairs([s.table for s in group], [s.k for s in group], [s.mask for s in group],
+                                    [s.fragment.dims for s in group], [(0, i) for i in range(1, len(group))], CELL)
+        for v, other in zip(votes, rest):
+            if v["valid"]:
+                off, cnt = (int(v["dx"]), int(v["dy"])), int(v["count"])
+                head.edges.append([True, off, cnt, other])       # snippet::bind, fgs.hpp:56-65
+                other.edges.append([False, (-off[0], -off[1]), cnt, head])
+
+    for i in range(len(snippets) - 1):  # match_all, fgs.hpp:135-140
+        match_partial(snippets[i], snippets[i + 1:])
+
+    while True:
+        best = None  # select_match: first maximum over primary edges in list order (fgs.hpp:142-163)
+        for s in snippets:
+            for e in s.edges:
+                if e[0] and (best is None or e[2] > best[1][2]):
+                    best = (s, e)
+        if best is None:
+            break
+        left, edge = best
+        right = edge[3]
+        dst = left.fragment
+        pos = (dst.zero[0] + edge[1][0], dst.zero[1] + edge[1][1])
+        dst.blit_fragment(mctx, pos, right.fragment)  # splice_single, fgs.hpp:165-183
+        dst.normalize()
+        merged = _extract_single(ctx_cache, dst, device)
+        for s in (right, left):  # unbind: drop the mirrored edges held by the others
+            for e in s.edges:
+                e[3].edges = [x for x in e[3].edges if x[3] is not s]
+        snippets = [merged] + [s for s in snippets if s is not right and s is not left]
+        match_partial(merged, snippets[1:])
+    out = [s.fragment for s in snippets]
+    for c in ctxs.values():
+        c.close()
+    return out
