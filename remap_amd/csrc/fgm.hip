@@ -72,39 +72,85 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
 }
 
 // ---- fgm::fragment::blit(pos, image, …) (fgm.hpp:87-97,176-188) -------------------------------
-// ++canvas[y+py-zy][x+px-zx][pixel] with uint16 wraparound.  Bins are packed two per dword;
-// the add is a 32-bit atomic on the containing dword and a carry out of the low half is
-// taken back, which keeps every bin exact modulo 2^16 (fgm.hpp:14).
+// ++canvas[y+py-zy][x+px-zx][pixel] with uint16 wraparound, for a whole batch of frames.
+// Output-centric: a workgroup OWNS a 128x8 tile of the canvas in LDS (32 B per pixel), walks
+// the batch's positions, and for every frame that covers the tile adds that frame's pixels
+// to its own bins — no atomics, every frame byte is read once (by the tile it lands in),
+// every canvas dot is read and written once.  Bins wrap modulo 2^16 exactly (fgm.hpp:14).
 struct BlitParams {
   const uint8_t* frames;
   const int32_t* pos;
   const uint32_t* frag_id;
   uint32_t* canvas;  // canvas_h x canvas_w x 8 dwords
-  uint32_t n, W, H, Wd;
+  uint32_t n, W, H;
   uint32_t fragment, cw, ch;
   int32_t zx, zy;
+  uint32_t tiles_x;
 };
 
+constexpr int BL_TW = 128, BL_TH = 8;
+
 __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
-  const uint32_t f = blockIdx.y;
-  if (p.frag_id && p.frag_id[f] != p.fragment) return;
-  const int64_t ax = (int64_t)p.pos[2 * f] - p.zx, ay = (int64_t)p.pos[2 * f + 1] - p.zy;
-  const uint8_t* src = p.frames + (size_t)f * p.W * p.H;
-  const uint32_t total = p.Wd * p.H;
-  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-    uint32_t y = i / p.Wd, xd = i - y * p.Wd;
-    uint32_t w = *reinterpret_cast<const uint32_t*>(src + (size_t)y * p.W + xd * 4);
-    uint32_t* row = p.canvas + ((size_t)(ay + y) * p.cw + (size_t)(ax + xd * 4)) * 8;
+  __shared__ uint32_t bins[BL_TW * BL_TH * 8];  // [row][x][8 dwords], 32 KB
+  __shared__ uint32_t list[256];
+  __shared__ uint32_t nlist;
+  const uint32_t tid = threadIdx.x;
+  const int tx0 = (int)(blockIdx.x % p.tiles_x) * BL_TW, ty0 = (int)(blockIdx.x / p.tiles_x) * BL_TH;
+  const int row = (int)(tid >> 5), xq = (int)(tid & 31u) * 4;  // this thread: 4 pixels of one row
+  const int X = tx0 + xq, Y = ty0 + row;                      // canvas coordinates
+  uint32_t* my = bins + ((size_t)row * BL_TW + xq) * 8;
+  // start from the canvas content (the canvas may already hold earlier batches)
+  const bool in_canvas_row = Y < (int)p.ch;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      uint32_t v = (w >> (8 * j)) & 0xfu;
-      uint32_t* word = row + j * 8 + (v >> 1);
-      if (v & 1u) {
-        atomicAdd(word, 0x10000u);  // high half: the carry leaves the dword
+  for (int j = 0; j < 4; ++j) {
+    const bool inside = in_canvas_row && X + j < (int)p.cw;
+    const uint4* src = reinterpret_cast<const uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
+    uint4 a = inside ? src[0] : make_uint4(0, 0, 0, 0), b = inside ? src[1] : make_uint4(0, 0, 0, 0);
+    reinterpret_cast<uint4*>(my + j * 8)[0] = a;
+    reinterpret_cast<uint4*>(my + j * 8)[1] = b;
+  }
+  const int W = (int)p.W, H = (int)p.H;
+  for (uint32_t base = 0; base < p.n; base += 256) {
+    __syncthreads();
+    if (tid == 0) nlist = 0;
+    __syncthreads();
+    const uint32_t f = base + tid;
+    if (f < p.n && (!p.frag_id || p.frag_id[f] == p.fragment)) {
+      const int ax = p.pos[2 * f] - p.zx, ay = p.pos[2 * f + 1] - p.zy;  // frame origin in the canvas
+      if (ax < tx0 + BL_TW && ax + W > tx0 && ay < ty0 + BL_TH && ay + H > ty0) list[atomicAdd(&nlist, 1u)] = f;
+    }
+    __syncthreads();
+    const uint32_t m = nlist;
+    for (uint32_t i = 0; i < m; ++i) {
+      const uint32_t g = list[i];
+      const int fx = X - (p.pos[2 * g] - p.zx), fy = Y - (p.pos[2 * g + 1] - p.zy);
+      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) continue;
+      const uint8_t* srow = p.frames + ((size_t)g * H + (size_t)fy) * W;
+      uint32_t w;
+      if (fx >= 0 && fx + 3 < W) {
+        __builtin_memcpy(&w, srow + fx, 4);  // unaligned dword
       } else {
-        uint32_t old = atomicAdd(word, 1u);
-        if ((old & 0xffffu) == 0xffffu) atomicSub(word, 0x10000u);  // undo the carry into the high bin
+        w = 0xffffffffu;  // 0xff marks "outside the frame"
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (fx + j >= 0 && fx + j < W) w = (w & ~(0xffu << (8 * j))) | ((uint32_t)srow[fx + j] << (8 * j));
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const uint32_t v = (w >> (8 * j)) & 0xffu;
+        if (v == 0xffu) continue;
+        uint32_t* word = my + j * 8 + ((v & 0xfu) >> 1);
+        const uint32_t old = *word;
+        *word = (v & 1u) ? old + 0x10000u : ((old & 0xffff0000u) | ((old + 1u) & 0xffffu));
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (in_canvas_row && X + j < (int)p.cw) {
+      uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
+      dst[0] = reinterpret_cast<uint4*>(my + j * 8)[0];
+      dst[1] = reinterpret_cast<uint4*>(my + j * 8)[1];
     }
   }
 }
