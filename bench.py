@@ -59,6 +59,24 @@ def cpu_baseline(frames_host):
                       f"{dt:.1f} s"}
 
 
+def pmc_traffic(n_local, dens):
+    """HBM bytes per kpe_main launch from the committed rocprofv3 --pmc passes of this same
+    workload (profiles/*_pmc_kpe_main.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py:
+    FETCH_SIZE doubled, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM).  None if the workload
+    differs from the profiled one (10 000 frames, dens 200) or no profile is committed."""
+    if n_local != FRAMES_PER_GPU or dens != DENS:
+        return None
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_main.json")))
+    if not files:
+        return None
+    try:
+        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +86,8 @@ def main():
     ap.add_argument("--dens", type=int, default=DENS)
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=10000)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the "
+                                                      "multi-rank flow on one GPU")
     args = ap.parse_args()
 
     import torch
@@ -87,8 +107,12 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "gloo":
+            local_rank = local_rank % max(1, torch.cuda.device_count())
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     L.load()
@@ -133,8 +157,11 @@ def main():
         out = al.align(frames, n_total=n_total)
     barrier()
     dt = time.perf_counter() - t0
-    ms_kpe = al.ctx.kernel_ms("kpe_main")
-    ms_parts = {k: al.ctx.kernel_ms(k) for k in ("kpe_table", "kpm_build", "kpm_match")}
+    ms_kpe = al.ctx.kernel_ms("kpe_main")          # average per launch
+    launches_per_step = al.ctx.kernel_launches("kpe_main") / max(1, args.steps)
+    # per-step totals of the other kernels (kpm_build / kpm_match run two instances each)
+    ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / max(1, args.steps)
+                for k in ("kpe_finish", "kpe_table", "kpm_build", "kpm_match")}
     al.ctx.set_timing(False)
 
     # tier B: + fgm blit into the fragment canvases (reported beside the headline)
@@ -147,14 +174,17 @@ def main():
     barrier()
     dtb = time.perf_counter() - t1
 
-    tmax = torch.tensor([dt, dtb], dtype=torch.float64, device=dev)
+    tmax = torch.tensor([dt, dtb], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt, dtb = float(tmax[0]), float(tmax[1])
 
     if rank == 0:
-        alg_bytes = 2.0 * W * H * n_local + 18.0 * ktot
+        # algorithmic bytes of one kpe_main launch: SURVEY.md §8d's per-frame figure
+        # (2*W*H + 18*K) x the frames one launch processes
+        alg_bytes = (2.0 * W * H * n_local + 18.0 * ktot) / max(1.0, launches_per_step)
         achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
+        traffic = pmc_traffic(n_local, args.dens) if launches_per_step == 1 else None
         line = {
             "metric": "aligned frames/s, 320x240 stream (kpe+kpm+frc), offsets bit-exact",
             "value": n_total * args.steps / dt,
@@ -177,7 +207,7 @@ def main():
             "frames_per_s_with_blit": n_total * nb / dtb,
             "kernel_ms": dict(kpe_main=ms_kpe, **ms_parts),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "kernel": "kpe_main",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "kpe_main",
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -30,6 +30,7 @@ struct rmx_ctx {
   uint32_t* kraw = nullptr;
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t n_cap = 0;
+  uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   KpmWorkspace kpm{};
@@ -163,6 +164,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   ctx->kmax = kmax;
   ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
   if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
+  if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess) {
     delete ctx;
@@ -317,7 +319,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     p.groups = (uint32_t)((p.V + 61) / 62);
     // strips (multiples of 8 rows): enough waves to fill the chip for small batches, long
     // strips (less halo-row re-reading) for big ones
-    uint32_t rps = 48;
+    uint32_t rps = ctx->rps_max;
     while (rps > 8 && (uint64_t)p.groups * ((ctx->H + rps - 1) / rps) < 16384) rps -= 8;
     p.rows_per_strip = rps;
     p.kmax = ctx->kmax;

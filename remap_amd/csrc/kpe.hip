@@ -183,10 +183,10 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   RowT T0, T1, T2;
   make_row(load_row(vy0 - 1), T0);
   make_row(load_row(vy0), T1);
-  // rows up to y+7 are prefetched (clamped to the frame)
-  uint32_t pf0 = load_row(vy0 + 1), pf1 = load_row(min(vy0 + 2, H - 1)), pf2 = load_row(min(vy0 + 3, H - 1)),
-           pf3 = load_row(min(vy0 + 4, H - 1)), pf4 = load_row(min(vy0 + 5, H - 1)),
-           pf5 = load_row(min(vy0 + 6, H - 1));
+  // rows up to y+7 are prefetched, clamped to the last row this strip needs (vy1): running
+  // past it would pull up to six rows per strip from HBM for nothing
+  uint32_t pf0 = load_row(vy0 + 1), pf1 = load_row(min(vy0 + 2, vy1)), pf2 = load_row(min(vy0 + 3, vy1)),
+           pf3 = load_row(min(vy0 + 4, vy1)), pf4 = load_row(min(vy0 + 5, vy1)), pf5 = load_row(min(vy0 + 6, vy1));
 
   uint32_t C = 0;
   // one output row: consume the prefetched row y+1, refill the prefetch slot with row y+7
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   {                                                                                      \
     const int yy = y + R;                                                                \
     make_row(PF, Cn);                                                                    \
-    PF = load_row(min(yy + 7, H - 1));                                                   \
+    PF = load_row(min(yy + 7, vy1));                                                   \
     uint32_t pk = merge_rows(A, B, Cn);                                                  \
     store_row(yy, pk & maskx);                                                           \
     uint32_t t = ((((pk ^ B.key) & maskx) + 0x0f0f0f0fu) & 0x10101010u);                 \

@@ -31,6 +31,22 @@ def shard_range(n_total: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _all_gather_flat(flat, world, dist, group):
+    """all_gather_into_tensor of a 1-D/2-D tensor along dim 0.  RCCL gathers device tensors
+    in place; the gloo backend (CPU tests, single-GPU rehearsals) gets a host round trip."""
+    import torch
+
+    out_shape = (world * flat.shape[0],) + tuple(flat.shape[1:])
+    if dist.get_backend(group) == "gloo" and flat.is_cuda:
+        host = flat.cpu()
+        out = torch.empty(out_shape, dtype=flat.dtype)
+        dist.all_gather_into_tensor(out, host, group=group)
+        return out.to(flat.device)
+    out = torch.empty(out_shape, dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(out, flat.contiguous(), group=group)
+    return out
+
+
 def gather_boundary_tables(last_desc, last_k, dist=None, group=None):
     """All-gather the last frame's descriptor table of every rank.
 
@@ -44,9 +60,7 @@ def gather_boundary_tables(last_desc, last_k, dist=None, group=None):
     world = dist.get_world_size(group)
     # one flat buffer per rank: [count (4 bytes, little endian) | table bytes]
     flat = torch.cat([last_k.reshape(1).to(torch.int32).view(torch.uint8), last_desc.reshape(-1)])
-    allf = torch.empty((world * flat.numel(),), dtype=torch.uint8, device=flat.device)
-    dist.all_gather_into_tensor(allf, flat.contiguous(), group=group)
-    allf = allf.view(world, -1)
+    allf = _all_gather_flat(flat.contiguous(), world, dist, group).view(world, -1)
     cnts = allf[:, :4].contiguous().view(torch.int32).reshape(world)
     tabs = allf[:, 4:].reshape((world,) + tuple(last_desc.shape))
     return tabs, cnts
@@ -64,9 +78,7 @@ def gather_offsets(dxdy, matched, counts, dist=None, group=None):
     pack = torch.zeros((m, 3), dtype=torch.int32, device=dxdy.device)
     pack[: dxdy.shape[0], :2] = dxdy
     pack[: dxdy.shape[0], 2] = matched.to(torch.int32)
-    allp = torch.empty((world * m, 3), dtype=torch.int32, device=dxdy.device)
-    dist.all_gather_into_tensor(allp, pack, group=group)
-    allp = allp.view(world, m, 3)
+    allp = _all_gather_flat(pack, world, dist, group).view(world, m, 3)
     parts = [allp[r, : counts[r]] for r in range(world)]
     cat = torch.cat(parts)
     return cat[:, :2].contiguous(), cat[:, 2].to(torch.uint8).contiguous()
