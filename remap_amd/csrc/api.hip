@@ -30,6 +30,7 @@ struct rmx_ctx {
   uint32_t* kraw = nullptr;
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t n_cap = 0;
+  uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
@@ -296,6 +297,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   if (!ctx || !frames || !median || !desc || !kcount || n == 0 || n > 0x0fffffffu) return RMX_ERR_ARG;
   RMX_HIP(hipSetDevice(ctx->device));
   if (int rc = ensure_workspace(ctx, n)) return rc;
+  ctx->n_last = n;
   RMX_HIP(hipMemsetAsync(ctx->kraw, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
   // Optional sub-batching (RMX_SUB_MIB): keeping frames + medians + candidate plane inside
   // the 256 MiB Infinity Cache between the streaming and the finishing pass was measured
@@ -360,18 +362,18 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
 int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k) {
   if (!ctx) return RMX_ERR_ARG;
   RMX_HIP(hipSetDevice(ctx->device));
-  uint32_t st[2] = {0, 0};
-  RMX_HIP(hipMemcpyAsync(st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+  uint32_t st = 0;
+  RMX_HIP(hipMemcpyAsync(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
   RMX_HIP(hipStreamSynchronize(ctx->stream));
-  if (max_k) {
+  if (max_k) {  // diagnostic: the per-frame counts are only fetched when asked for
     *max_k = 0;
-    if (ctx->n_cap) {
-      std::vector<uint32_t> k(ctx->n_cap);
-      RMX_HIP(hipMemcpy(k.data(), ctx->kraw, (size_t)ctx->n_cap * 4, hipMemcpyDeviceToHost));
+    if (ctx->n_last) {
+      std::vector<uint32_t> k(ctx->n_last);
+      RMX_HIP(hipMemcpy(k.data(), ctx->kraw, (size_t)ctx->n_last * 4, hipMemcpyDeviceToHost));
       for (uint32_t v : k) *max_k = std::max(*max_k, v);
     }
   }
-  if (st[0]) {
+  if (st) {
     RMX_HIP(hipMemsetAsync(ctx->status, 0, sizeof(uint32_t), ctx->stream));
     return RMX_ERR_KMAX;
   }

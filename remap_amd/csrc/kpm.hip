@@ -53,6 +53,16 @@ __device__ __forceinline__ uint64_t fnv_offset(int32_t x, int32_t y) {
 // count reaches the previous bucket count (measured with g++ 11.4, see
 // tests/test_umap_order.py; hashtable_c++0x.cc _M_need_rehash/_M_next_bkt).
 __device__ const uint32_t kUmapBuckets[12] = {13, 29, 59, 127, 257, 541, 1109, 2357, 5087, 10273, 20753, 42043};
+// floor((2^64 - 1) / bucket count): Barrett reduction instead of a software 64-bit division
+__device__ const uint64_t kUmapMagic[12] = {0x13b13b13b13b13b1ull, 0x8d3dcb08d3dcb08ull, 0x456c797dd49c341ull, 0x204081020408102ull, 0xff00ff00ff00ffull, 0x79237d65bcce50ull, 0x3b183cf0fed886ull, 0x1bce09c66f6fc3ull, 0xce20e98148847ull, 0x661230fdfb43eull, 0x3286c744cba2bull, 0x18f0c8989d637ull};
+
+// h mod kUmapBuckets[level], exact: q = mulhi(h, M) is floor(h / B) or up to 2 less.
+__device__ __forceinline__ uint32_t umap_bucket(uint64_t h, int level) {
+  const uint32_t B = kUmapBuckets[level];
+  uint64_t r = h - __umul64hi(h, kUmapMagic[level]) * B;
+  while (r >= B) r -= B;
+  return (uint32_t)r;
+}
 
 // Iteration order of a libstdc++ unordered_map after inserting keys with 64-bit hashes
 // h[0..n-1] in index order (oracle: orc_umap_order).  Sequential; called by ONE lane.
@@ -72,7 +82,7 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
       head = NONE;
       while (p != NONE) {  // _M_rehash_aux
         uint32_t nx = next[p];
-        uint32_t b = (uint32_t)(h[p] % Bn);
+        uint32_t b = umap_bucket(h[p], level);
         uint32_t before = bucket[b];
         if (before == NONE) {
           next[p] = (uint16_t)head;
@@ -92,12 +102,12 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
       B = Bn;
     }
     // _M_insert_bucket_begin
-    uint32_t b = (uint32_t)(h[i] % B);
+    uint32_t b = umap_bucket(h[i], level);
     uint32_t before = bucket[b];
     if (before == NONE) {
       next[i] = (uint16_t)head;
       head = i;
-      if (next[i] != NONE) bucket[(uint32_t)(h[next[i]] % B)] = (uint16_t)i;
+      if (next[i] != NONE) bucket[umap_bucket(h[next[i]], level)] = (uint16_t)i;
       bucket[b] = (uint16_t)BEFORE;
     } else if (before == BEFORE) {
       next[i] = (uint16_t)head;
@@ -123,6 +133,8 @@ enum { H_E = 0, H_G = 1, H_POFF = 2, H_GOFF = 3, H_HTOFF = 4, H_HTMASK = 5, H_W2
 struct KpmWorkspace {
   uint32_t* pool = nullptr;  // (n_cap + 1) frames x stride_u32
   uint32_t* tickets = nullptr;  // n_cap pairs x 8 regions x 3 x 2 (key, count)
+  uint32_t* needs_large = nullptr;  // n_cap + 1 flags written by kpm_build_small
+  uint32_t* work = nullptr;         // 1 + n_cap * 8 work items for kpm_match<LARGE>
   uint32_t n_cap = 0, kmax = 0;
   size_t bytes = 0;
 };
@@ -137,6 +149,8 @@ inline size_t kpm_workspace_bytes(const KpmWorkspace& w) { return w.bytes; }
 inline void kpm_workspace_free(KpmWorkspace& w) {
   if (w.pool) (void)hipFree(w.pool);
   if (w.tickets) (void)hipFree(w.tickets);
+  if (w.needs_large) (void)hipFree(w.needs_large);
+  if (w.work) (void)hipFree(w.work);
   w = KpmWorkspace{};
 }
 
@@ -209,11 +223,10 @@ __device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
   __syncthreads();
 }
 
-// Two instances share the batch: <256, 64> (one wave, 19 KB of LDS, many per CU) takes the
-// frames with at most 256 keypoints, <2048, 256> the rest; each exits at once on frames of
-// the other class.
+// General instance (one workgroup per frame, regions one after the other).  It runs after
+// kpm_build_small and takes only the frames that kernel marked in `needs_large`.
 template <uint32_t KC, uint32_t NT, uint32_t GPOOL, uint32_t BUCKETS>
-__global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p) {
+__global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large) {
   __shared__ uint16_t ent[KC];       // scan indices of the region's entries, scan order
   __shared__ uint16_t slot_of[KC];   // hash slot of entry i
   __shared__ uint16_t gid_of[KC];    // rank of a group's first entry -> group id
@@ -232,7 +245,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p) {
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
-  if (KC == 256 ? k > 256 : k <= 256) return;  // the other instance's frame (uniform)
+  if (needs_large && !needs_large[fslot]) return;  // built by kpm_build_small (uniform)
   uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
   uint32_t* hdr = pool;
   uint32_t* pts = pool + kpm_off_pts(p.kmax);
@@ -351,14 +364,175 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p) {
   }
 }
 
+// ---- small frames: one wave per region ---------------------------------------------------------------
+// Frames with at most 256 keypoints and at most 64 entries in every region (the common case:
+// the synthetic streams have ~10 entries per region) are built by kpm_build_small: eight
+// waves, wave r owns region r, everything wave-synchronous (ballot compaction, a 64-key
+// bitonic sort in registers, one lane replaying libstdc++'s node order), two block barriers
+// to exchange the regions' sizes.  It runs before kpm_build<2048,...>, which then takes
+// only the frames marked in `needs_large`.
+constexpr uint32_t KS_RC = 64;  // entries per region
+
+__global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_t* needs_large) {
+  __shared__ uint16_t ent[8][KS_RC];
+  __shared__ uint32_t htl[8][2 * KS_RC];
+  __shared__ uint64_t hg[8][KS_RC];
+  __shared__ uint16_t nxt[8][KS_RC], bkt[8][127 + 3], gid_of[8][KS_RC];
+  __shared__ uint32_t s_e[8], s_g[8], s_goff[8];
+  __shared__ uint32_t s_big;
+
+  const uint32_t fslot = blockIdx.x;
+  const bool is_halo = fslot == p.n;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
+  if (k > p.kmax) k = p.kmax;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t EMPTY = 0xffffffffu;
+  if (threadIdx.x == 0) s_big = k > 256 ? 1u : 0u;
+  __syncthreads();
+  const bool mine = r < p.nreg && k <= 256;
+  // 1. region entries in scan order
+  uint32_t e = 0;
+  if (mine) {
+    for (uint32_t base = 0; base < k; base += 64) {
+      uint32_t i = base + lane;
+      bool in = i < k && ((desc[i].region_mask >> r) & 1u);
+      uint64_t bal = __builtin_amdgcn_ballot_w64(in);
+      uint32_t pos = e + mbcnt(bal);
+      if (in && pos < KS_RC) ent[r][pos] = (uint16_t)i;
+      e += (uint32_t)__builtin_popcountll(bal);
+    }
+    if (e > KS_RC && lane == 0) atomicOr(&s_big, 1u);
+  }
+  __syncthreads();
+  if (s_big) {  // uniform for the block
+    if (threadIdx.x == 0) needs_large[fslot] = 1u;
+    return;
+  }
+  if (threadIdx.x == 0) needs_large[fslot] = 0u;
+  // 2. group by code (slot value = smallest entry rank with that code), weights
+  uint32_t c[4] = {0, 0, 0, 0}, myslot = 0, w2 = 0, w1 = 0, slots = 16, G = 0, gid = 0, first = 0;
+  bool start = false;
+  uint32_t key = 0xffffffffu;
+  if (mine) {
+    while (slots < 2 * e) slots <<= 1;
+    const uint32_t mask = slots - 1;
+    for (uint32_t s = lane; s < slots; s += 64) htl[r][s] = EMPTY;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane < e) {
+      load_code(desc + ent[r][lane], c);
+      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      for (;;) {
+        uint32_t v = atomicCAS(&htl[r][s], EMPTY, lane);
+        if (v == EMPTY) break;
+        uint32_t c2[4];
+        load_code(desc + ent[r][v], c2);
+        if (same_code(c, c2)) {
+          atomicMin(&htl[r][s], lane);
+          break;
+        }
+        s = (s + 1) & mask;
+      }
+      myslot = s;
+    }
+    w2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < e && (c[3] & 0xfu) == 2u));
+    w1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < e && (c[3] & 0xfu) == 1u));
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    // 3. order entries by (first occurrence of their code, scan order): bitonic sort of one key per lane
+    if (lane < e) key = htl[r][myslot] << 16 | lane;
+#pragma unroll
+    for (uint32_t kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
+        bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+        key = (lower == up) ? min(key, other) : max(key, other);
+      }
+    // 4. groups in first-occurrence order
+    const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
+    start = lane < e && (lane == 0 || (key >> 16) != (prev >> 16));
+    const uint64_t sb = __builtin_amdgcn_ballot_w64(start);
+    G = (uint32_t)__builtin_popcountll(sb);
+    gid = mbcnt(sb);  // group id of a start lane
+    first = key >> 16;
+    if (lane == 0) {
+      s_e[r] = e;
+      s_g[r] = G;
+    }
+  } else if (lane == 0 && r < 8) {
+    s_e[r] = 0;
+    s_g[r] = 0;
+  }
+  __syncthreads();
+  if (!mine) {
+    __syncthreads();  // pairs with the barrier before the replay below
+    return;
+  }
+  // pool offsets: exclusive sums over the regions before this one
+  uint32_t p_off = 0, g_off = 0, ht_off = 0;
+  for (uint32_t q = 0; q < r; ++q) {
+    p_off += s_e[q];
+    g_off += s_g[q];
+    uint32_t sl = 16;
+    while (sl < 2 * s_e[q]) sl <<= 1;
+    ht_off += sl;
+  }
+  uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
+  uint32_t* pts = pool + kpm_off_pts(p.kmax);
+  uint32_t* gstart = pool + kpm_off_gstart(p.kmax);
+  uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
+  uint32_t* ght = pool + kpm_off_ht(p.kmax);
+  if (lane < e) {
+    const rmx_desc* d = desc + ent[r][key & 0xffffu];
+    pts[p_off + lane] = (uint32_t)d->x | (uint32_t)d->y << 16;
+    if (start) {
+      gstart[g_off + r + gid] = p_off + lane;
+      gfirst[g_off + gid] = ent[r][first];
+      uint32_t cf[4];
+      load_code(desc + ent[r][first], cf);
+      hg[r][gid] = fnv_code(cf);
+      gid_of[r][first] = (uint16_t)gid;  // rank of a group's first entry -> group id
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // export the code index: slot -> group id + 1
+  for (uint32_t sidx = lane; sidx < slots; sidx += 64) {
+    uint32_t v = htl[r][sidx];
+    ght[ht_off + sidx] = v == EMPTY ? 0u : (uint32_t)gid_of[r][v] + 1u;
+  }
+  if (lane == 0) {
+    gstart[g_off + r + G] = p_off + e;
+    uint32_t* h = pool + r * 8;
+    h[H_E] = e;
+    h[H_G] = G;
+    h[H_POFF] = p_off;
+    h[H_GOFF] = g_off;
+    h[H_HTOFF] = ht_off;
+    h[H_HTMASK] = slots - 1;
+    h[H_W2] = w2;
+    h[H_W1] = w1;
+    s_goff[r] = g_off;
+  }
+  __syncthreads();
+  // iteration order of the eight code maps: eight lanes of one wave replay libstdc++ side by side
+  if (threadIdx.x < p.nreg) {
+    const uint32_t q = threadIdx.x;
+    umap_order_seq(hg[q], s_g[q], nxt[q], bkt[q], pool + kpm_off_giter(p.kmax) + s_goff[q]);
+  }
+}
+
 // ---- matching --------------------------------------------------------------------------------------
-constexpr uint32_t KM_NEEDS_LARGE = 0xffffffffu;  // ticket[0] marker left by the small instance
 
 struct KpmMatchParams {
   const rmx_desc* desc;
   const rmx_desc* halo_desc;
   const uint32_t* pool;
   uint32_t* tickets;  // pairs x nreg x 3 x {key, count}
+  uint32_t* work;     // [0] = count, [1..] = (pair * nreg + region) items left to the large instance
   uint32_t* status;
   uint32_t n, kmax, nreg;
   uint32_t has_halo;
@@ -382,7 +556,7 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
 // Two instances: SMALL (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
 // LDS, ~20 waves per CU) runs first on every (pair, region) and leaves the marker
-// KM_NEEDS_LARGE in the ticket when a limit is hit; the LARGE instance (2048 / 1024 / 1024)
+// the item in the work list when a limit is hit; the LARGE instance (2048 / 1024 / 1024)
 // then redoes exactly those.
 template <bool SMALL, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
@@ -393,14 +567,16 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint64_t skey[KM_DMAX];
 
   const uint32_t lane = threadIdx.x;
-  const uint32_t q = blockIdx.x / p.nreg, r = blockIdx.x % p.nreg;
+  // SMALL: one (pair, region) per workgroup.  LARGE: a fixed grid walks the work list the
+  // small instance appended to (no launch of n*8 mostly empty workgroups).
+  const uint32_t it_end = SMALL ? blockIdx.x + 1 : p.work[0];
+  for (uint32_t it = blockIdx.x; it < it_end; it += gridDim.x) {
+  const uint32_t item = SMALL ? it : p.work[1 + it];
+  const uint32_t q = item / p.nreg, r = item % p.nreg;
   uint32_t* ticket = p.tickets + ((size_t)q * p.nreg + r) * 6;
-  if (!SMALL) {
-    if (ticket[0] != KM_NEEDS_LARGE) return;  // the small instance finished this one
-  }
   __builtin_amdgcn_wave_barrier();
   if (lane < 6) ticket[lane] = 0;
-  if (q == 0 && !p.has_halo) return;
+  if (q == 0 && !p.has_halo) continue;
   const uint32_t stride = kpm_stride_u32(p.kmax);
   const uint32_t pslot = q == 0 ? p.n : q - 1;
   const uint32_t* P = p.pool + (size_t)pslot * stride;
@@ -410,7 +586,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   const uint32_t* ph = P + r * 8;
   const uint32_t* ch = Cc + r * 8;
   const uint32_t Gc = ch[H_G];
-  if (Gc == 0 || ph[H_G] == 0) return;
+  if (Gc == 0 || ph[H_G] == 0) continue;
   // kpm.hpp:219-222: all codes unless both regions are rich in weight-2 keypoints
   const bool use_all = ph[H_W2] < p.weight_switch || ch[H_W2] <= p.weight_switch;
   const uint32_t* c_gstart = Cc + kpm_off_gstart(p.kmax) + ch[H_GOFF] + r;
@@ -472,13 +648,13 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   if (overflow) {
     if (lane == 0) {
       if (SMALL)
-        ticket[0] = KM_NEEDS_LARGE;
+        p.work[1 + atomicAdd(&p.work[0], 1u)] = item;
       else
         atomicOr(&p.status[1], 2u);
     }
-    return;
+    continue;
   }
-  if (nm == 0) return;
+  if (nm == 0) continue;
   if (lane == 0) mg_base[nm] = total;
   for (uint32_t s = lane; s < KM_HSLOTS; s += 64) {
     hk[s] = 0;
@@ -525,11 +701,11 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   if (D > KM_DMAX) {
     if (lane == 0) {
       if (SMALL)
-        ticket[0] = KM_NEEDS_LARGE;
+        p.work[1 + atomicAdd(&p.work[0], 1u)] = item;
       else
         atomicOr(&p.status[1], 4u);
     }
-    return;
+    continue;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
@@ -565,7 +741,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
       ticket[2 * lane] = hk[s];
       ticket[2 * lane + 1] = hc[s];
     }
-    return;
+    continue;
   }
   // exact path: insertion order of the totalizator = order of first occurrence among pairs
   // compact distinct offsets
@@ -634,6 +810,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
       ticket[2 * rdx + 1] = hc[s];
     }
   }
+  }  // work items
 }
 
 struct KpmDeclareParams {

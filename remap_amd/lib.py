@@ -200,7 +200,9 @@ class Context:
                                          kcount.data_ptr()), "rmx_kpe_batch")
         return median, desc, kcount
 
-    def kpe_status(self):
+    def kpe_status(self, want_max=True):
+        if not want_max:
+            return self.lib.rmx_kpe_status(self.h, None), 0
         mk = C.c_uint32()
         rc = self.lib.rmx_kpe_status(self.h, C.byref(mk))
         return rc, mk.value

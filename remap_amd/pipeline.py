@@ -139,8 +139,9 @@ class Aligner:
         out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
                    lo=lo, hi=hi, nfrag=carry[1] + 1)
         if check:
-            rc, maxk = ctx.kpe_status()
+            rc, _ = ctx.kpe_status(want_max=False)
             if rc:
+                _, maxk = ctx.kpe_status()
                 raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
             rc, fl = ctx.kpm_status()
             if rc:
