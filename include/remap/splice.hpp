@@ -1,0 +1,189 @@
+// remap/splice.hpp — namespaces fgs and mpb of the reference on top of the C ABI.
+//
+//   fgs::splice(first, last)                     (fgs.hpp:187-213)
+//   mpb::builder<Adapter>::collect / splice      (mpb.hpp:52-68; the stages around them —
+//                                                  aws, fdf, arf — are outside this path)
+//
+// Pixels and keypoints stay on the device: a snippet is a fragment (canvas in HBM) plus its
+// blend mask and single-region descriptor table, both device buffers produced by
+// rmx_fgm_blend and rmx_kpe_batch (grid 1x1, overlap 0: fgs.hpp:17,85); candidate pairs are
+// scored by rmx_kpm_cell_pairs (cellular kpm::match, kpm.hpp:371-393).  The greedy merge
+// loop is sequential by nature and stays on the host, with the reference's list/edge ORDER
+// (select_match takes the first maximum, fgs.hpp:142-163).
+#pragma once
+
+#include <iterator>
+#include <list>
+#include <string>
+#include <vector>
+
+#include "collector.hpp"
+
+namespace fgs {
+
+namespace details {
+
+inline constexpr std::uint32_t snippet_kmax = 2048;
+inline constexpr kpm::cell_size_t cell_size{15, 15};  // fgs.hpp:121
+
+struct snippet;
+using snippet_list = std::list<snippet>;
+using snippet_iterator_t = snippet_list::iterator;
+
+struct delta {
+  bool primary_;
+  kpm::vote vote_;
+  snippet_iterator_t other_;
+};
+
+struct snippet {
+  fgm::fragment fragment_;
+  remap::device_buffer mask_;   // dim.area() bytes, non-zero where the canvas has content
+  remap::device_buffer table_;  // snippet_kmax rmx_desc rows
+  std::uint32_t count_{0};
+  std::list<delta> edges_;
+};
+
+// fgs.hpp:80-89 — blend the canvas, extract keypoints of the blended image (one region)
+inline snippet extract_single(fgm::fragment&& fragment) {
+  snippet s{std::move(fragment), {}, {}, 0, {}};
+  const auto dim = s.fragment_.dimensions();
+  rmx_ctx* c = remap::context_cache::get(std::uint32_t(dim.width_), std::uint32_t(dim.height_), 1, 1, 0, snippet_kmax);
+  const std::size_t area = dim.area();
+  remap::device_buffer image{c, area}, median{c, area}, kcount{c, 16};
+  s.mask_ = remap::device_buffer{c, area};
+  s.table_ = remap::device_buffer{c, snippet_kmax * sizeof(rmx_desc)};
+  if (s.fragment_.device_canvas()) {
+    remap::check(rmx_fgm_blend(c, s.fragment_.device_canvas(), std::uint32_t(dim.width_), std::uint32_t(dim.height_),
+                               image.get<std::uint8_t>(), s.mask_.get<std::uint8_t>()),
+                 c, "rmx_fgm_blend");
+  } else {
+    remap::check(rmx_memset(c, image.get(), 0, area), c, "rmx_memset");
+    remap::check(rmx_memset(c, s.mask_.get(), 0, area), c, "rmx_memset");
+  }
+  remap::check(rmx_kpe_batch(c, image.get<std::uint8_t>(), 1, median.get<std::uint8_t>(), s.table_.get<rmx_desc>(),
+                             kcount.get<std::uint32_t>()),
+               c, "rmx_kpe_batch");
+  remap::check(rmx_kpe_status(c, nullptr), c, "rmx_kpe_status");
+  remap::check(rmx_download(c, &s.count_, kcount.get(), 4), c, "rmx_download");
+  return s;
+}
+
+// fgs.hpp:119-133 — head against every snippet of [first, last): one device call for all pairs
+template <typename It>
+void match_partial(It head, It first, It last) {
+  std::vector<It> others;
+  for (; first != last; ++first) others.push_back(first);
+  if (others.empty()) return;
+  std::vector<rmx_desc const*> tables{head->table_.template get<rmx_desc>()};
+  std::vector<std::uint32_t> counts{head->count_}, dims, pairs;
+  std::vector<std::uint8_t const*> masks{head->mask_.template get<std::uint8_t>()};
+  auto push_dims = [&](fgm::fragment const& f) {
+    dims.push_back(std::uint32_t(f.dimensions().width_));
+    dims.push_back(std::uint32_t(f.dimensions().height_));
+  };
+  push_dims(head->fragment_);
+  for (std::size_t i = 0; i < others.size(); ++i) {
+    tables.push_back(others[i]->table_.template get<rmx_desc>());
+    counts.push_back(others[i]->count_);
+    masks.push_back(others[i]->mask_.template get<std::uint8_t>());
+    push_dims(others[i]->fragment_);
+    pairs.push_back(0);
+    pairs.push_back(std::uint32_t(i + 1));
+  }
+  rmx_ctx* c = remap::context_cache::get(16, 8, 1, 1, 0, snippet_kmax);
+  std::vector<rmx_vote> votes(others.size());
+  remap::check(rmx_kpm_cell_pairs(c, tables.data(), counts.data(), masks.data(), dims.data(),
+                                  std::uint32_t(tables.size()), pairs.data(), std::uint32_t(others.size()),
+                                  cell_size.width_, cell_size.height_, votes.data()),
+               c, "rmx_kpm_cell_pairs");
+  for (std::size_t i = 0; i < others.size(); ++i)
+    if (votes[i].valid) {  // snippet::bind, fgs.hpp:56-65: a primary edge here, the reversed one there
+      kpm::vote v{{votes[i].dx, votes[i].dy}, votes[i].count};
+      head->edges_.push_back(delta{true, v, others[i]});
+      others[i]->edges_.push_back(delta{false, v.reverse(), head});
+    }
+}
+
+template <typename It>
+void match_all(It first, It last) {  // fgs.hpp:135-140
+  if (first == last) return;
+  for (auto rest = std::next(first); rest != last; ++first, ++rest) match_partial(first, rest, last);
+}
+
+inline void unbind(snippet_iterator_t self) {  // fgs.hpp:67-71: drop the mirrored edges held by the others
+  for (auto& e : self->edges_) e.other_->edges_.remove_if([&](delta const& d) { return d.other_ == self; });
+}
+
+}  // namespace details
+
+template <typename Iter>
+std::vector<fgm::fragment> splice(Iter first, Iter last) {
+  using namespace details;
+  snippet_list snippets;
+  for (; first != last; ++first) snippets.push_back(extract_single(std::move(*first)));  // extract_all
+  match_all(snippets.begin(), snippets.end());
+  for (;;) {
+    // select_match (fgs.hpp:142-163): first maximum of the vote count over primary edges
+    snippet_iterator_t left = snippets.end();
+    delta* edge = nullptr;
+    for (auto it = snippets.begin(); it != snippets.end(); ++it)
+      for (auto& e : it->edges_)
+        if (e.primary_ && (!edge || e.vote_.count_ > edge->vote_.count_)) {
+          left = it;
+          edge = &e;
+        }
+    if (!edge) break;
+    // splice_single (fgs.hpp:165-183)
+    auto right = edge->other_;
+    auto& dst = left->fragment_;
+    dst.blit(dst.zero() + edge->vote_.offset_, std::move(right->fragment_));
+    dst.normalize();
+    snippets.push_front(extract_single(std::move(dst)));
+    unbind(right);
+    unbind(left);
+    snippets.erase(right);
+    snippets.erase(left);
+    match_partial(snippets.begin(), std::next(snippets.begin()), snippets.end());
+  }
+  std::vector<fgm::fragment> result;
+  result.reserve(snippets.size());
+  for (auto& s : snippets) result.push_back(std::move(s.fragment_));
+  return result;
+}
+
+}  // namespace fgs
+
+namespace mpb {
+
+// The two stages of mpb::builder that lie on the hot path (mpb.hpp:52-68), with the
+// reference's adapter contract: get_compression(), get_callbacks().  build() of the
+// reference also runs aws (before) and fdf/arf (after), which are outside this path.
+template <typename Adapter>
+class builder {
+public:
+  using adapter_type = Adapter;
+  using feed_type = typename Adapter::feed_type;
+
+  builder(adapter_type const& adapter) noexcept : adapter_{adapter} {}
+
+  auto collect(feed_type& feed, mrl::dimensions_t const& window) {
+    frc::collector collector{window};
+    collector.collect(feed, adapter_.get_compression(), cb());
+    auto result = collector.complete();
+    cb()(std::string{"frc"}, result);
+    return result;
+  }
+
+  auto splice(std::list<fgm::fragment>& fragments) {
+    auto result = fgs::splice(fragments.begin(), fragments.end());
+    cb()(std::string{"spl"}, result);
+    return result;
+  }
+
+private:
+  auto& cb() noexcept { return adapter_.get_callbacks(); }
+  adapter_type adapter_;
+};
+
+}  // namespace mpb

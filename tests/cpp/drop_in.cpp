@@ -9,6 +9,7 @@
 #include <string>
 
 #include "frc.hpp"
+#include "mpb.hpp"
 
 // same shape as main.cpp's file_feed (main.cpp:16-52), reading from one memory blob
 class mem_feed {
@@ -36,6 +37,58 @@ struct noop_compression {
   }
 };
 
+// an adapter with the members mpb::builder uses on this path (main.cpp:194-244)
+struct counting_callbacks {
+  std::size_t frames{0};
+  std::size_t collected{0}, spliced{0};
+  void operator()(fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) noexcept {
+    ++frames;
+  }
+  void operator()(std::string const& tag, std::list<fgm::fragment> const& f) noexcept {
+    if (tag == "frc") collected = f.size();
+  }
+  void operator()(std::string const& tag, std::vector<fgm::fragment> const& f) noexcept {
+    if (tag == "spl") spliced = f.size();
+  }
+};
+class mem_adapter {
+public:
+  using callbacks_type = counting_callbacks;
+  using feed_type = mem_feed;
+  noop_compression get_compression() const { return {}; }
+  callbacks_type& get_callbacks() noexcept { return callbacks_; }
+
+private:
+  callbacks_type callbacks_{};
+};
+
+static unsigned long long canvas_sum(fgm::fragment const& f) {
+  auto dots = f.dots();
+  unsigned long long s = 0;
+  for (auto const* d = dots.data(); d < dots.end(); ++d)
+    for (int b = 0; b < 16; ++b) s = s * 1000003ull + (*d)[b];
+  return s;
+}
+
+// mpb::builder::collect + splice (mpb.hpp:52-68) over a memory feed
+static int run_splice(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob) {
+  mpb::builder<mem_adapter> builder{mem_adapter{}};
+  mem_feed feed{dim, blob};
+  auto fragments = builder.collect(feed, dim);
+  std::printf("collected %zu\n", fragments.size());
+  auto spliced = builder.splice(fragments);
+  std::printf("spliced %zu\n", spliced.size());
+  std::size_t fi = 0;
+  for (auto& f : spliced) {
+    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu\n", fi, f.dimensions().width_,
+                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), canvas_sum(f));
+    for (auto& fr : f.frames())
+      std::printf("frame %zu frag %zu pos %d %d\n", fr.number_, fi, fr.position_.x_, fr.position_.y_);
+    ++fi;
+  }
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -50,6 +103,7 @@ int main(int argc, char** argv) {
   std::ifstream in(argv[1], std::ios::binary);
   std::vector<std::uint8_t> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
   mrl::dimensions_t dim{W, H};
+  if (argc > 4 && std::string(argv[4]) == "splice") return run_splice(dim, blob);
 
   frc::collector collector{dim};
   std::size_t calls = 0, entries = 0, last_no = 0;

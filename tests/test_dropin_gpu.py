@@ -73,3 +73,28 @@ def test_collector_drop_in_matches_oracle(gpu, tmp_path):
     d0 = O.orc_kpe(frames[0])[1]
     assert int(pair[2]) == sum(bin(int(x)).count("1") for x in d0["region_mask"])
     assert int(pair[4]) == m and (int(pair[6]), int(pair[7])) == d
+
+
+def test_builder_collect_splice_drop_in_matches_reference(gpu, tmp_path):
+    """mpb::builder::collect + splice through the drop-in headers == the reference's golden
+    fgs::splice result (tests/golden/fgs_splice.npz)."""
+    from remap_amd.synth import rooms_v1
+
+    exe = build_driver(str(tmp_path))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fgs_splice.npz"))
+    n, w, h, rooms, dens, seed = g["gen"].tolist()
+    frames, _, _ = rooms_v1(n, width=w, height=h, n_rooms=rooms, dens=dens, seed=seed)
+    blob = tmp_path / "rooms.bin"
+    frames.tofile(blob)
+    out = subprocess.run([exe, str(blob), str(w), str(h), "splice"], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().splitlines()
+    assert lines[0] == f"collected {int(g['ncollected'])}" and lines[1] == f"spliced {int(g['nfrag'])}"
+    frag_lines = [l.split() for l in lines if l.startswith("fragment ")]
+    frame_lines = [l.split() for l in lines if l.startswith("frame ")]
+    assert len(frame_lines) == n
+    for k, fl in enumerate(frag_lines):
+        assert [int(fl[3]), int(fl[4])] == g["dims"][k].tolist()
+        assert int(fl[11]) == int(g["canvas_sum"][k])
+    for fl in frame_lines:
+        no, k = int(fl[1]), int(fl[3])
+        assert int(g["frag"][no]) == k and [int(fl[5]), int(fl[6])] == g["pos"][no].tolist()
