@@ -122,7 +122,8 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
 }
 
 // ---- per-frame region tables -----------------------------------------------------------------------
-constexpr uint32_t KPM_KMAX = 2048;     // descriptor-table stride supported by the matcher
+constexpr uint32_t KPM_KMAX = 2048;     // entries per REGION the general build instance holds
+constexpr uint32_t KPM_TABLE_MAX = 16384;  // descriptor-table stride (kmax) supported by the matcher
 constexpr uint32_t KPM_GPOOL = 4096;    // groups per frame summed over regions (LDS pool)
 constexpr uint32_t KPM_BUCKETS = 2357;  // bucket scratch per region (covers 2048 groups)
 constexpr uint32_t HDR_U32 = 64;        // 8 regions x 8 words
@@ -266,7 +267,13 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
     for (uint32_t i = i0; i < i1; ++i) cnt += (desc[i].region_mask >> r) & 1u;
     uint32_t e = 0;
     uint32_t w = block_exscan<NT>(cnt, scan_scratch, &e);
-    for (uint32_t i = i0; i < i1; ++i)
+    if (e > KC) {  // more entries in one region than this instance holds: reported, region left empty
+      if (tid == 0) atomicOr(&p.status[1], 64u);
+      e = 0;
+      w = 0;
+      cnt = 0;
+    }
+    for (uint32_t i = i0; i < i1 && cnt; ++i)
       if ((desc[i].region_mask >> r) & 1u) ent[w++] = (uint16_t)i;
     uint32_t slots = 16;
     while (slots < 2 * e) slots <<= 1;

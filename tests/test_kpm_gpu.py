@@ -110,3 +110,14 @@ def test_frc_scan_matches_oracle(gpu):
     assert np.array_equal(torch.cat([p1, p2]).cpu().numpy(), o["pos"])
     assert np.array_equal(torch.cat([f1, f2]).cpu().numpy().astype(np.uint32), o["frag"])
     assert c2 == carry
+
+
+def test_kpm_large_tables_kmax_8192(gpu):
+    # frames with thousands of keypoints (noise blocks) and a table stride above 2048
+    rng = np.random.default_rng(21)
+    base = np.kron(rng.integers(0, 16, size=(30, 50), dtype=np.uint8), np.ones((8, 8), np.uint8))
+    for x0 in (40, 210):  # two noisy bands in different column regions (~2.8k keypoints per frame)
+        base[:, x0:x0 + 10] = rng.integers(0, 16, size=(240, 10), dtype=np.uint8)
+    frames = np.stack([np.ascontiguousarray(base[:, x:x + 320]) for x in (0, 2, 5, 5, 9)])
+    g, _ = check_seq(frames, kmax=8192)
+    assert max(len(t) for t in g["tabs"]) > 2048
