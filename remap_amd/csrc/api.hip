@@ -85,7 +85,7 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   ctx->kraw = nullptr;
   ctx->cand = nullptr;
   ctx->n_cap = 0;
-  const size_t cand_bytes = (size_t)n * ((ctx->H + 7) / 8) * (ctx->W / 4) * sizeof(uint32_t);
+  const size_t cand_bytes = (size_t)n * ((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * sizeof(uint32_t);
   RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
   RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->cand, cand_bytes));
@@ -137,9 +137,9 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
                    uint32_t overlap, uint32_t kmax, void* stream, rmx_ctx** out) {
   if (!out) return RMX_ERR_ARG;
   *out = nullptr;
-  // W % 4: a lane owns one aligned dword of a row.  Lower bounds: the band arithmetic of
+  // Any width: a lane owns one dword of a row (the last one may be partial).  Lower bounds: the band arithmetic of
   // kpe.hpp:84-90 needs every region to start inside the frame.  x,y are uint16 in rmx_desc.
-  if (width % 4 || width < 16 || height < 8 || width > 65532 || height > 65535) return RMX_ERR_ARG;
+  if (width < 16 || height < 8 || width > 65532 || height > 65535) return RMX_ERR_ARG;
   if (grid_w < 1 || grid_h < 1 || grid_w > 4 || grid_h > 4 || grid_w * grid_h > 8) return RMX_ERR_ARG;
   if (kmax < 1 || kmax > 16384) return RMX_ERR_ARG;
   {
@@ -303,7 +303,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   // the 256 MiB Infinity Cache between the streaming and the finishing pass was measured
   // SLOWER at every size (small launches cost more than the re-reads), so the default is
   // one launch pair for the whole batch.
-  const size_t per_frame = (size_t)ctx->W * ctx->H * 2 + (size_t)((ctx->H + 7) / 8) * (ctx->W / 4) * 4;
+  const size_t per_frame = (size_t)ctx->W * ctx->H * 2 + (size_t)((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * 4;
   uint32_t sub = (uint32_t)std::max<size_t>(1, ((size_t)ctx->sub_mib << 20) / per_frame);
   for (uint32_t f0 = 0; f0 < n; f0 += sub) {
     const uint32_t m = std::min(sub, n - f0);
@@ -316,7 +316,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     p.n = m;
     p.W = ctx->W;
     p.H = ctx->H;
-    p.Wd = ctx->W / 4;
+    p.Wd = (ctx->W + 3) / 4;
     p.V = (uint64_t)m * p.Wd;
     p.groups = (uint32_t)((p.V + 61) / 62);
     // strips (multiples of 8 rows): enough waves to fill the chip for small batches, long
@@ -330,7 +330,10 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
     {
       Timer t(ctx, &ctx->ms_kpe);
-      hipLaunchKernelGGL(kpe_main, grid, dim3(256), 0, ctx->stream, p);
+      if (ctx->W % 4 == 0)
+        hipLaunchKernelGGL(kpe_main<true>, grid, dim3(256), 0, ctx->stream, p);
+      else
+        hipLaunchKernelGGL(kpe_main<false>, grid, dim3(256), 0, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
     {

@@ -122,6 +122,10 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 // frames -> median + candidate bit plane (1 bit per pixel: centre != 4th largest of 3x3).
 // Candidate word layout: one dword per (frame, 8-row block yb, dword column c); bit
 // 8*j + ((r + 4) & 7) flags pixel x = 4c + j, y = 8*yb + r.
+// ALIGNED = frame width is a multiple of 4.  Otherwise rows start at unaligned bytes (the
+// loads simply are unaligned dwords), the last dword column of a row is partial, and its
+// median bytes are stored one by one so the next row's first pixels are not overwritten.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -144,8 +148,12 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   const uint32_t f0 = (uint32_t)(Lb / p.Wd);
   const size_t frame_bytes = (size_t)p.W * p.H;
   const uint32_t voff = (uint32_t)((size_t)(f - f0) * frame_bytes) + c * 4;  // < 3 frames
-  const rsrc_t rin = make_rsrc(p.frames + (size_t)f0 * frame_bytes, 0x7fffffffu);
-  const rsrc_t rout = make_rsrc(p.median + (size_t)f0 * frame_bytes, 0x7fffffffu);
+  // the descriptors end where the batch ends: a partial last dword of the batch reads 0
+  const size_t left = (size_t)(p.n - f0) * frame_bytes;
+  const uint32_t recs = (uint32_t)(left < 0x7fffffffull ? left : 0x7fffffffull);
+  const rsrc_t rin = make_rsrc(p.frames + (size_t)f0 * frame_bytes, recs);
+  const rsrc_t rout = make_rsrc(p.median + (size_t)f0 * frame_bytes, recs);
+  const uint32_t part = ALIGNED ? 0u : (c == p.Wd - 1 ? (p.W & 3u) : 0u);  // valid bytes of a partial dword
   const rsrc_t rcand = make_rsrc(p.cand + (size_t)f0 * p.HB * p.Wd, 0x7fffffffu);
   const uint32_t voff_st = lane_ok ? voff : 0xffffffffu;  // dropped by the range check
   const uint32_t voff_c = lane_ok ? ((f - f0) * p.HB * p.Wd + c) * 4 : 0xffffffffu;
@@ -167,7 +175,12 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
     return (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(rin, voff, (uint32_t)(y * W), 0);
   };
   auto store_row = [&](int y, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, (uint32_t)(y * W), 0);
+    if (!ALIGNED && part) {
+      for (uint32_t j = 0; j < part; ++j)
+        __builtin_amdgcn_raw_buffer_store_b8((uint8_t)(v >> (8 * j)), rout, voff_st + j, (uint32_t)(y * W), 0);
+    } else {
+      __builtin_amdgcn_raw_buffer_store_b32(v, rout, voff_st, (uint32_t)(y * W), 0);
+    }
   };
   auto store_cand = [&](int yb, uint32_t v) {
     __builtin_amdgcn_raw_buffer_store_b32(v, rcand, voff_c, (uint32_t)(yb * (int)p.Wd * 4), 0);

@@ -90,3 +90,22 @@ def test_blit_uint16_wraparound(gpu):
             exp[y, x, frame[y, x]] = n % 65536
     assert np.array_equal(got, exp)
     ctx.close()
+
+
+def test_blit_odd_width(gpu):
+    import torch
+
+    rng = np.random.default_rng(8)
+    W, H, n = 133, 41, 30
+    frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
+    pos = np.cumsum(rng.integers(-9, 10, size=(n, 2)), axis=0).astype(np.int32)
+    pos[0] = 0
+    ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+    cw, ch, zx, zy = ctx.fgm_extent(pos)
+    ocan = np.zeros((ch, cw, 16), np.uint16)
+    for i in range(n):
+        O.orc_fgm_blit(ocan, (zx, zy), frames[i], pos[i])
+    canvas = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+    ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy))
+    assert np.array_equal(canvas.cpu().numpy().view(np.uint16), ocan)
+    ctx.close()

@@ -91,3 +91,15 @@ def test_kpe_many_frames_matches_single(gpu):
         m1, t1 = run_kpe(frames[i:i + 1])
         assert np.array_equal(med[i], m1[0])
         assert tabs[i].tobytes() == t1[0].tobytes()
+
+
+def test_kpe_widths_not_multiple_of_four(gpu):
+    # cropped windows have arbitrary widths (main.cpp crops the feed to the action window)
+    rng = np.random.default_rng(17)
+    for (H, W, grid, ov) in [(41, 133, (1, 1), 0), (60, 322, (4, 2), 16), (48, 161, (4, 2), 16), (37, 23, (1, 1), 0),
+                             (64, 130, (4, 2), 16), (50, 127, (4, 2), 16)]:
+        base = rng.integers(0, 16, size=(H // 5 + 1, W // 5 + 1), dtype=np.uint8)
+        img = np.kron(base, np.ones((5, 5), np.uint8))[:H, :W]
+        noise = rng.integers(0, 16, size=(H, W), dtype=np.uint8)
+        frames = np.ascontiguousarray(np.stack([img, np.roll(img, 2, axis=1), noise, np.roll(img, 3, axis=0)]))
+        check_against_oracle(frames, grid=grid, overlap=ov, kmax=16384)
