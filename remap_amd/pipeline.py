@@ -151,9 +151,12 @@ class Aligner:
         return out
 
     def blit(self, frames, pos, frag, lo, hi):
-        """fgm::fragment::blit of this rank's frames into per-fragment canvases sized from
-        the GLOBAL positions (every rank allocates the same boxes; summing the per-rank
-        canvases with uint16 wraparound gives the reference canvas, fgm.hpp:99-113)."""
+        """fgm::fragment::blit of this rank's frames.  For every fragment with frames on this
+        rank the GLOBAL canvas box (zero, dims) follows from all positions of the fragment
+        (fgm.hpp:190-233); the rank accumulates only the step-aligned sub-box its own frames
+        touch.  Returns {fragment: (canvas, zero, (global_w, global_h, global_zero))}: adding
+        every rank's sub-canvas at (zero - global_zero) with uint16 wraparound gives the
+        reference canvas (fgm.hpp:99-113); with one rank the sub-box is the whole box."""
         t = self.torch
         pos_h = pos.cpu().numpy()
         frag_h = frag.cpu().numpy()
@@ -163,7 +166,14 @@ class Aligner:
         frag_l = frag[lo:hi].contiguous()
         for fid in local_frags:
             sel = frag_h == fid
-            cw, ch, zx, zy = self.ctx.fgm_extent(pos_h[sel])
+            gw, gh, gzx, gzy = self.ctx.fgm_extent(pos_h[sel])
+            loc = pos_h[lo:hi][frag_h[lo:hi] == fid]
+            # step-aligned sub-box (in steps from the global zero) covering the local frames
+            x0 = (int(loc[:, 0].min()) - gzx) // self.W * self.W
+            y0 = (int(loc[:, 1].min()) - gzy) // self.H * self.H
+            x1 = -((-(int(loc[:, 0].max()) + self.W - gzx)) // self.W) * self.W
+            y1 = -((-(int(loc[:, 1].max()) + self.H - gzy)) // self.H) * self.H
+            cw, ch, zx, zy = x1 - x0, y1 - y0, gzx + x0, gzy + y0
             key = ("canvas", int(fid))
             c = self._bufs.get(key)
             if c is None or tuple(c.shape) != (ch, cw, 16):
@@ -171,7 +181,7 @@ class Aligner:
                 self._bufs[key] = c
             c.zero_()
             self.ctx.fgm_blit(frames, pos_l, c, (zx, zy), frag_id=frag_l, fragment=int(fid))
-            canvases[int(fid)] = (c, (zx, zy))
+            canvases[int(fid)] = (c, (zx, zy), (gw, gh, (gzx, gzy)))
         return canvases
 
     def close(self):

@@ -109,3 +109,32 @@ def test_blit_odd_width(gpu):
     ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy))
     assert np.array_equal(canvas.cpu().numpy().view(np.uint16), ocan)
     ctx.close()
+
+
+def test_sharded_blit_sums_to_the_whole_canvas(gpu):
+    # two "ranks" blit their halves into sub-canvases; adding them at their offsets inside the
+    # global box (uint16 wraparound) must give the single-rank canvas
+    import torch
+    from remap_amd.pipeline import Aligner
+
+    frames, _ = scroller_v1(60, dens=80)
+    frames = frames.copy()
+    frames[25] = 6  # a fragment break inside the first shard
+    al = Aligner(320, 240)
+    d = torch.from_numpy(frames).cuda()
+    out = al.align(d, blit=True)
+    whole = {k: (v[0].clone(), v[1], v[2]) for k, v in out["canvases"].items()}
+    parts = []
+    for lo, hi in ((0, 31), (31, 60)):
+        al._bufs = {k: v for k, v in al._bufs.items() if not (isinstance(k, tuple) and k[0] == "canvas")}
+        parts.append({k: (v[0].clone(), v[1], v[2]) for k, v in al.blit(d[lo:hi], out["pos"], out["frag"], lo, hi).items()})
+    for fid, (canvas, zero, (gw, gh, gz)) in whole.items():
+        assert tuple(canvas.shape[:2]) == (gh, gw) and zero == gz
+        acc = torch.zeros_like(canvas)
+        for part in parts:
+            if fid in part:
+                c, z, g = part[fid]
+                assert g == (gw, gh, gz)
+                al.ctx.fgm_merge(acc, c, (z[0] - gz[0], z[1] - gz[1]))
+        assert torch.equal(acc, canvas), fid
+    al.close()

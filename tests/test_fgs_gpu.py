@@ -61,7 +61,7 @@ def test_collect_then_splice_matches_reference(gpu):
     assert out["nfrag"] == int(g["ncollected"])
     frags = []
     for fid in range(out["nfrag"]):
-        canvas, zero = out["canvases"][fid]
+        canvas, zero, _ = out["canvases"][fid]
         idx = np.nonzero(frag == fid)[0]
         f = Fragment(canvas.clone(), zero, (w, h), [(int(i), pos[i]) for i in idx])
         f.normalize()  # collector.complete(), frc.hpp:74-80
