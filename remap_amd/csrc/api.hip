@@ -35,6 +35,8 @@ struct rmx_ctx {
   uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   KpmWorkspace kpm{};
+  uint32_t* blit_ws = nullptr;  // fgm_blit binning workspace
+  size_t blit_ws_bytes = 0;
   size_t ws_bytes = 0;
   // timing: HIP event pairs recorded on the context stream around each kernel launch,
   // resolved (averaged) only when rmx_last_kernel_ms is called — no host sync in between
@@ -183,6 +185,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->status) (void)hipFree(ctx->status);
+  if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
   delete ctx;

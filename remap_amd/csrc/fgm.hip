@@ -74,7 +74,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
 // ---- fgm::fragment::blit(pos, image, …) (fgm.hpp:87-97,176-188) -------------------------------
 // ++canvas[y+py-zy][x+px-zx][pixel] with uint16 wraparound, for a whole batch of frames.
 // Output-centric: a workgroup OWNS a 128x8 tile of the canvas in LDS (32 B per pixel), walks
-// the batch's positions, and for every frame that covers the tile adds that frame's pixels
+// the frames binned to its tile column, and for every frame that covers the tile adds that frame's pixels
 // to its own bins — no atomics, every frame byte is read once (by the tile it lands in),
 // every canvas dot is read and written once.  Bins wrap modulo 2^16 exactly (fgm.hpp:14).
 struct BlitParams {
@@ -86,19 +86,70 @@ struct BlitParams {
   uint32_t fragment, cw, ch;
   int32_t zx, zy;
   uint32_t tiles_x;
+  // frames binned by the tile COLUMNS they overlap (built by blit_bin_* below)
+  uint32_t* col_cnt;   // tiles_x + 1: counts, then exclusive offsets (in place)
+  uint32_t* col_cur;   // tiles_x fill cursors
+  uint32_t* col_list;  // frame ids, <= n * (W / 128 + 2)
 };
 
 constexpr int BL_TW = 128, BL_TH = 8;
 
+// A frame overlaps at most W/128 + 2 tile columns; three tiny passes bin the batch's frames
+// by tile column so that a tile walks ~(W + 128) / (mean step) frames instead of all n.
+__global__ __launch_bounds__(256) void blit_bin_count(BlitParams p) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= p.n || (p.frag_id && p.frag_id[f] != p.fragment)) return;
+  const int ax = p.pos[2 * f] - p.zx;
+  const int t0 = max(ax, 0) / BL_TW, t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+  for (int t = t0; t <= t1; ++t) atomicAdd(&p.col_cnt[t], 1u);
+}
+__global__ __launch_bounds__(1024) void blit_bin_scan(BlitParams p) {
+  __shared__ uint32_t part[1024];
+  const uint32_t tid = threadIdx.x, n = p.tiles_x;
+  const uint32_t chunk = (n + 1023) / 1024, i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
+  uint32_t s = 0;
+  for (uint32_t i = i0; i < i1; ++i) s += p.col_cnt[i];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < 1024; ++t) {
+      uint32_t v = part[t];
+      part[t] = acc;
+      acc += v;
+    }
+    p.col_cnt[n] = acc;
+  }
+  __syncthreads();
+  uint32_t acc = part[tid];
+  for (uint32_t i = i0; i < i1; ++i) {
+    uint32_t v = p.col_cnt[i];
+    p.col_cnt[i] = acc;
+    p.col_cur[i] = acc;
+    acc += v;
+  }
+}
+__global__ __launch_bounds__(256) void blit_bin_fill(BlitParams p) {
+  const uint32_t f = blockIdx.x * 256 + threadIdx.x;
+  if (f >= p.n || (p.frag_id && p.frag_id[f] != p.fragment)) return;
+  const int ax = p.pos[2 * f] - p.zx;
+  const int t0 = max(ax, 0) / BL_TW, t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+  for (int t = t0; t <= t1; ++t) p.col_list[atomicAdd(&p.col_cur[t], 1u)] = f;
+}
+
 __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
-  __shared__ uint32_t bins[BL_TW * BL_TH * 8];  // [row][x][8 dwords], 32 KB
+  // bins[k][slot]: dword k (bins 2k, 2k+1) of the pixel in `slot`; a thread's pixel j sits in
+  // slot row*128 + j*32 + (tid & 31), so for any k the 32 lanes of a half-wave hit 32
+  // different banks whatever colours they carry (a [pixel][8] layout is a 32-way conflict)
+  __shared__ uint32_t bins[8][BL_TW * BL_TH];  // 32 KB
   __shared__ uint32_t list[256];
+  __shared__ int list_ax[256], list_ay[256];  // canvas origin of the listed frames
   __shared__ uint32_t nlist;
   const uint32_t tid = threadIdx.x;
   const int tx0 = (int)(blockIdx.x % p.tiles_x) * BL_TW, ty0 = (int)(blockIdx.x / p.tiles_x) * BL_TH;
   const int row = (int)(tid >> 5), xq = (int)(tid & 31u) * 4;  // this thread: 4 pixels of one row
   const int X = tx0 + xq, Y = ty0 + row;                      // canvas coordinates
-  uint32_t* my = bins + ((size_t)row * BL_TW + xq) * 8;
+  const uint32_t slot0 = (uint32_t)row * BL_TW + (tid & 31u);
   // start from the canvas content (the canvas may already hold earlier batches)
   const bool in_canvas_row = Y < (int)p.ch;
 #pragma unroll
@@ -106,51 +157,84 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
     const bool inside = in_canvas_row && X + j < (int)p.cw;
     const uint4* src = reinterpret_cast<const uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
     uint4 a = inside ? src[0] : make_uint4(0, 0, 0, 0), b = inside ? src[1] : make_uint4(0, 0, 0, 0);
-    reinterpret_cast<uint4*>(my + j * 8)[0] = a;
-    reinterpret_cast<uint4*>(my + j * 8)[1] = b;
+    const uint32_t sl = slot0 + (uint32_t)j * 32;
+    bins[0][sl] = a.x;
+    bins[1][sl] = a.y;
+    bins[2][sl] = a.z;
+    bins[3][sl] = a.w;
+    bins[4][sl] = b.x;
+    bins[5][sl] = b.y;
+    bins[6][sl] = b.z;
+    bins[7][sl] = b.w;
   }
   const int W = (int)p.W, H = (int)p.H;
-  for (uint32_t base = 0; base < p.n; base += 256) {
+  const uint32_t tcol = blockIdx.x % p.tiles_x;
+  const uint32_t lbeg = p.col_cnt[tcol], lend = p.col_cnt[tcol + 1];  // this tile column's frames
+  for (uint32_t base = lbeg; base < lend; base += 256) {
     __syncthreads();
     if (tid == 0) nlist = 0;
     __syncthreads();
-    const uint32_t f = base + tid;
-    if (f < p.n && (!p.frag_id || p.frag_id[f] == p.fragment)) {
-      const int ax = p.pos[2 * f] - p.zx, ay = p.pos[2 * f + 1] - p.zy;  // frame origin in the canvas
-      if (ax < tx0 + BL_TW && ax + W > tx0 && ay < ty0 + BL_TH && ay + H > ty0) list[atomicAdd(&nlist, 1u)] = f;
+    if (base + tid < lend) {
+      const uint32_t f = p.col_list[base + tid];
+      const int ax = p.pos[2 * f] - p.zx, ay = p.pos[2 * f + 1] - p.zy;  // x overlap is guaranteed by the column list
+      if (ay < ty0 + BL_TH && ay + H > ty0) {
+        const uint32_t at = atomicAdd(&nlist, 1u);
+        list[at] = f;
+        list_ax[at] = ax;
+        list_ay[at] = ay;
+      }
     }
     __syncthreads();
     const uint32_t m = nlist;
-    for (uint32_t i = 0; i < m; ++i) {
+    // eight frames per trip: all loads are issued before the first LDS update, so the load
+    // latency is paid once per eight frames instead of once per frame
+    auto fetch = [&](uint32_t i) -> uint32_t {
+      if (i >= m) return 0xffffffffu;  // 0xff in every byte = "outside the frame"
       const uint32_t g = list[i];
-      const int fx = X - (p.pos[2 * g] - p.zx), fy = Y - (p.pos[2 * g + 1] - p.zy);
-      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) continue;
+      const int fx = X - list_ax[i], fy = Y - list_ay[i];
+      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return 0xffffffffu;
       const uint8_t* srow = p.frames + ((size_t)g * H + (size_t)fy) * W;
       uint32_t w;
       if (fx >= 0 && fx + 3 < W) {
         __builtin_memcpy(&w, srow + fx, 4);  // unaligned dword
-      } else {
-        w = 0xffffffffu;  // 0xff marks "outside the frame"
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (fx + j >= 0 && fx + j < W) w = (w & ~(0xffu << (8 * j))) | ((uint32_t)srow[fx + j] << (8 * j));
+        return w & 0x0f0f0f0fu;
       }
+      w = 0xffffffffu;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (fx + j >= 0 && fx + j < W) w = (w & ~(0xffu << (8 * j))) | ((uint32_t)(srow[fx + j] & 0xfu) << (8 * j));
+      return w;
+    };
+    auto apply = [&](uint32_t w) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t v = (w >> (8 * j)) & 0xffu;
         if (v == 0xffu) continue;
-        uint32_t* word = my + j * 8 + ((v & 0xfu) >> 1);
+        uint32_t* word = &bins[v >> 1][slot0 + (uint32_t)j * 32];
         const uint32_t old = *word;
         *word = (v & 1u) ? old + 0x10000u : ((old & 0xffff0000u) | ((old + 1u) & 0xffffu));
       }
+    };
+    for (uint32_t i = 0; i < m; i += 8) {
+      const uint32_t w0 = fetch(i), w1 = fetch(i + 1), w2 = fetch(i + 2), w3 = fetch(i + 3), w4 = fetch(i + 4),
+                     w5 = fetch(i + 5), w6 = fetch(i + 6), w7 = fetch(i + 7);
+      apply(w0);
+      apply(w1);
+      apply(w2);
+      apply(w3);
+      apply(w4);
+      apply(w5);
+      apply(w6);
+      apply(w7);
     }
   }
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     if (in_canvas_row && X + j < (int)p.cw) {
+      const uint32_t sl = slot0 + (uint32_t)j * 32;
       uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
-      dst[0] = reinterpret_cast<uint4*>(my + j * 8)[0];
-      dst[1] = reinterpret_cast<uint4*>(my + j * 8)[1];
+      dst[0] = make_uint4(bins[0][sl], bins[1][sl], bins[2][sl], bins[3][sl]);
+      dst[1] = make_uint4(bins[4][sl], bins[5][sl], bins[6][sl], bins[7][sl]);
     }
   }
 }
