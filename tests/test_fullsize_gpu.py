@@ -1,0 +1,51 @@
+"""BASELINE.json's full size (10 000 frames 320x240) through size-independent properties:
+ground-truth offsets of the generator, batch invariance (one batch == four batches chained
+by halo tables and the scan carry), and oracle spot checks on sampled frames."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dens", [200, 40])
+def test_ten_thousand_frames(gpu, dens):
+    import torch
+
+    n = 10000
+    frames, truth = scroller_v1(n, dens=dens)
+    ctx = L.Context(320, 240, kmax=2048)
+    d = torch.from_numpy(frames).cuda()
+    med, desc, kc = ctx.kpe(d)
+    assert ctx.kpe_status()[0] == 0
+    dxdy, matched = ctx.kpm_seq(desc, kc)
+    assert ctx.kpm_status()[0] == 0
+    pos, frag, carry = ctx.frc_scan(dxdy, matched)
+    dx = dxdy.cpu().numpy()
+    assert matched.cpu().numpy()[1:].all() and np.array_equal(dx[1:], truth[1:])
+    assert carry[1] == 0 and np.array_equal(pos.cpu().numpy()[:, 0], np.cumsum(truth[:, 0]))
+    # batch invariance: four chunks, each matched against the previous chunk's last table
+    cuts = [0, 2500, 5000, 7777, n]
+    parts_d, parts_m, parts_p = [], [], []
+    cr = None
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        m2, d2, k2 = ctx.kpe(d[a:b])
+        halo = None if a == 0 else (desc[a - 1], kc[a - 1:a])
+        dd, mm = ctx.kpm_seq(d2, k2, halo=halo)
+        pp, ff, cr = ctx.frc_scan(dd, mm, first_is_start=(a == 0), carry=cr)
+        assert torch.equal(m2, med[a:b]) and torch.equal(k2, kc[a:b])
+        parts_d.append(dd)
+        parts_m.append(mm)
+        parts_p.append(pp)
+    assert torch.equal(torch.cat(parts_d), dxdy) and torch.equal(torch.cat(parts_m), matched)
+    assert torch.equal(torch.cat(parts_p), pos) and cr == carry
+    # oracle spot checks
+    tabs_k = kc.cpu().numpy()
+    for i in (0, 1, 4999, 9999):
+        omed, odesc, k = O.orc_kpe(frames[i])
+        assert k == tabs_k[i] and np.array_equal(med[i].cpu().numpy(), omed)
+        assert desc[i, :k].cpu().numpy().tobytes() == odesc.tobytes()
+    ctx.close()

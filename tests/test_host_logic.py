@@ -113,3 +113,21 @@ def test_no_gpu_means_loud_failure():
     import pytest
     with pytest.raises(L.RemapError):
         L.Context(320, 240)
+
+
+def test_ctx_create_rejects_bad_arguments_without_a_gpu():
+    import ctypes as C
+    so = L.load()
+    h = C.c_void_p()
+    bad = [(8, 240, 4, 2, 16, 64),       # too narrow
+           (320, 4, 4, 2, 16, 64),       # too low
+           (320, 240, 0, 2, 16, 64),     # empty grid
+           (320, 240, 4, 4, 16, 64),     # more than 8 regions
+           (320, 240, 4, 2, 16, 0),      # kmax 0
+           (320, 240, 4, 2, 16, 1 << 20),  # kmax too large
+           (64, 24, 4, 2, 16, 64)]       # 4x2 bands do not fit (kpe.hpp:84-90)
+    for a in bad:
+        assert so.rmx_ctx_create(0, *a, None, C.byref(h)) == -1, a
+    assert so.rmx_ctx_create(0, 320, 240, 4, 2, 16, 64, None, None) == -1
+    assert so.rmx_kpe_batch(None, None, 0, None, None, None) == -1
+    assert so.rmx_fgm_extent(None, 0, 320, 240, None, None, None, None) == -1
