@@ -17,7 +17,7 @@
 // Bit-exactness.  top_offsets keeps the FIRST-ITERATED offset among equal counts
 // (kpm.hpp:138, strict >), iterating a std::unordered_map, so the ticket depends on
 // libstdc++'s node order.  That order is a deterministic function of the insertion
-// sequence and the hashes: umap_order_seq() below replays libstdc++'s
+// sequence and the hashes: umap_order_seq() / umap_order_par() below replay libstdc++'s
 // _M_insert_bucket_begin / _M_rehash_aux (GCC 11) on the device.  It needs the offsets in
 // the order the reference first touches them, i.e. in pair-enumeration order, which in
 // turn follows the iteration order of the current region's code map — hence the two
@@ -121,11 +121,84 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
   for (uint32_t p = head; p != NONE; p = next[p]) order[k++] = (OutT)p;
 }
 
+// The same order without pointer chasing.  libstdc++ puts a node at the front of its bucket
+// and a new bucket at the front of the list, for inserts and for rehashes alike, so the list
+// after (re)building with B buckets from a sequence S is S sorted by (first position of the
+// element's bucket in S, descending; own position in S, descending).  Level by level — S =
+// previous list order followed by the elements inserted while that bucket count was live —
+// this is a handful of parallel passes (bucket index, atomicMin per bucket, bitonic sort)
+// instead of thousands of dependent LDS round trips.  Verified against a real
+// std::unordered_map through the oracle (tests/test_host_logic.py restates it in numpy).
+//   NT threads cooperate (a wave with a wave barrier, or a workgroup with __syncthreads);
+//   scratch: keys[pow2 >= n] u32, seq_a/seq_b[n] u16, bmin[final bucket count] u32.
+struct WaveBarrier {
+  __device__ __forceinline__ void operator()() const {
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
+};
+struct BlockBarrier {
+  __device__ __forceinline__ void operator()() const { __syncthreads(); }
+};
+
+template <uint32_t NT, typename Bar, typename OutT>
+__device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* keys, uint16_t* seq_a, uint16_t* seq_b,
+                                      uint32_t* bmin, Bar bar, OutT* order, uint32_t tid) {
+  uint16_t* cur = seq_a;
+  uint16_t* nxt = seq_b;
+  uint32_t nk = 0;
+  for (int level = 0;; ++level) {
+    const uint32_t B = kUmapBuckets[level], mk = min(B, n);
+    for (uint32_t b = tid; b < B; b += NT) bmin[b] = 0xffffffffu;
+    bar();
+    for (uint32_t t = tid; t < mk; t += NT) {
+      const uint32_t e = t < nk ? cur[t] : t;
+      atomicMin(&bmin[umap_bucket(h[e], level)], t);
+    }
+    bar();
+    uint32_t n2 = 1;
+    while (n2 < mk) n2 <<= 1;
+    for (uint32_t t = tid; t < n2; t += NT) {
+      uint32_t key = 0xffffffffu;
+      if (t < mk) {
+        const uint32_t e = t < nk ? cur[t] : t;
+        key = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
+      }
+      keys[t] = key;
+    }
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        bar();
+        for (uint32_t i = tid; i < n2; i += NT) {
+          const uint32_t ixj = i ^ j;
+          if (ixj > i) {
+            const uint32_t x = keys[i], y = keys[ixj];
+            if ((x > y) == ((i & k) == 0)) {
+              keys[i] = y;
+              keys[ixj] = x;
+            }
+          }
+        }
+      }
+    bar();
+    for (uint32_t j = tid; j < mk; j += NT) {
+      const uint32_t t = 0xffffu - (keys[j] & 0xffffu);
+      nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
+    }
+    bar();
+    uint16_t* sw = cur;
+    cur = nxt;
+    nxt = sw;
+    nk = mk;
+    if (mk == n) break;
+  }
+  for (uint32_t j = tid; j < n; j += NT) order[j] = (OutT)cur[j];
+}
+
 // ---- per-frame region tables -----------------------------------------------------------------------
-constexpr uint32_t KPM_KMAX = 2048;     // entries per REGION the general build instance holds
+constexpr uint32_t KPM_KMAX = 4096;     // entries (and code groups) per REGION the general build instance holds
 constexpr uint32_t KPM_TABLE_MAX = 16384;  // descriptor-table stride (kmax) supported by the matcher
-constexpr uint32_t KPM_GPOOL = 4096;    // groups per frame summed over regions (LDS pool)
-constexpr uint32_t KPM_BUCKETS = 2357;  // bucket scratch per region (covers 2048 groups)
+constexpr uint32_t KPM_BUCKETS = 5087;  // bucket scratch (covers 4096 groups)
 constexpr uint32_t HDR_U32 = 64;        // 8 regions x 8 words
 
 // header words per region
@@ -226,19 +299,17 @@ __device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
 
 // General instance (one workgroup per frame, regions one after the other).  It runs after
 // kpm_build_small and takes only the frames that kernel marked in `needs_large`.
-template <uint32_t KC, uint32_t NT, uint32_t GPOOL, uint32_t BUCKETS>
+template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
 __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large) {
   __shared__ uint16_t ent[KC];       // scan indices of the region's entries, scan order
   __shared__ uint16_t slot_of[KC];   // hash slot of entry i
   __shared__ uint16_t gid_of[KC];    // rank of a group's first entry -> group id
   __shared__ uint32_t htl[2 * KC];   // slot -> smallest entry rank with that code
   __shared__ uint32_t keys[KC];
-  __shared__ uint64_t hg[GPOOL];     // group hashes in insertion order, pooled over regions
-  __shared__ uint16_t nxt[GPOOL];
-  __shared__ uint16_t bkt[8][BUCKETS + 3];
+  __shared__ uint64_t hg[KC];        // the current region's group hashes in insertion order
+  __shared__ uint16_t seq_a[KC], seq_b[KC];
+  __shared__ uint32_t bmin[BUCKETS];
   __shared__ uint32_t scan_scratch[8];
-  __shared__ uint32_t gl_off[9];           // region offsets into hg/nxt
-  __shared__ uint32_t gg_off[8];           // region offsets into the frame's group arrays
   __shared__ uint32_t s_w2, s_w1;
 
   const uint32_t fslot = blockIdx.x;  // 0..n-1 frames of the batch, n = halo
@@ -256,8 +327,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
   const uint32_t tid = threadIdx.x;
   const uint32_t EMPTY = 0xffffffffu;
 
-  uint32_t p_off = 0, g_off = 0, ht_off = 0, gl = 0;  // running pool offsets (uniform)
-  if (tid == 0) gl_off[0] = 0;
+  uint32_t p_off = 0, g_off = 0, ht_off = 0;  // running pool offsets (uniform)
   const uint32_t seg = (k + NT - 1) / NT;  // contiguous entries per thread
 
   for (uint32_t r = 0; r < p.nreg; ++r) {
@@ -318,7 +388,6 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
     for (uint32_t j = j0; j < j1; ++j) starts += (j == 0 || (keys[j] >> 16) != (keys[j - 1] >> 16));
     uint32_t G = 0;
     uint32_t gid = block_exscan<NT>(starts, scan_scratch, &G);
-    const bool fits = gl + G <= GPOOL && G <= KC;
     for (uint32_t j = j0; j < j1; ++j) {
       uint32_t first = keys[j] >> 16, i = keys[j] & 0xffffu;
       const rmx_desc* d = desc + ent[i];
@@ -327,11 +396,9 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
         gstart[g_off + r + gid] = p_off + j;
         gfirst[g_off + gid] = ent[first];
         gid_of[first] = (uint16_t)gid;
-        if (fits) {
-          uint32_t c[4];
-          load_code(desc + ent[first], c);
-          hg[gl + gid] = fnv_code(c);
-        }
+        uint32_t c[4];
+        load_code(desc + ent[first], c);
+        hg[gid] = fnv_code(c);
         ++gid;
       }
     }
@@ -352,22 +419,14 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
       h[H_HTMASK] = mask;
       h[H_W2] = s_w2;
       h[H_W1] = s_w1;
-      if (!fits) atomicOr(&p.status[1], 1u);
-      gl_off[r + 1] = fits ? gl + G : gl;
-      gg_off[r] = g_off;
     }
+    __syncthreads();
+    // 6. iteration order of this region's code map (keys[] is free again)
+    umap_order_par<NT>(hg, G, keys, seq_a, seq_b, bmin, BlockBarrier{}, pool + kpm_off_giter(p.kmax) + g_off, tid);
     p_off += e;
     g_off += G;
     ht_off += slots;
-    if (fits) gl += G;
     __syncthreads();
-  }
-  // 6. iteration order of every region's code map: lane r replays libstdc++ for region r
-  if (tid < p.nreg) {
-    const uint32_t r = tid;
-    const uint32_t a = gl_off[r], G = gl_off[r + 1] - a;
-    uint32_t* giter = pool + kpm_off_giter(p.kmax) + gg_off[r];
-    umap_order_seq(hg + a, G, nxt + a, bkt[r], giter);
   }
 }
 
@@ -384,8 +443,9 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   __shared__ uint16_t ent[8][KS_RC];
   __shared__ uint32_t htl[8][2 * KS_RC];
   __shared__ uint64_t hg[8][KS_RC];
-  __shared__ uint16_t nxt[8][KS_RC], bkt[8][127 + 3], gid_of[8][KS_RC];
-  __shared__ uint32_t s_e[8], s_g[8], s_goff[8];
+  __shared__ uint16_t seq_a[8][KS_RC], seq_b[8][KS_RC], gid_of[8][KS_RC];
+  __shared__ uint32_t okeys[8][KS_RC], bmin[8][127];
+  __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big;
 
   const uint32_t fslot = blockIdx.x;
@@ -474,10 +534,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     s_g[r] = 0;
   }
   __syncthreads();
-  if (!mine) {
-    __syncthreads();  // pairs with the barrier before the replay below
-    return;
-  }
+  if (!mine) return;
   // pool offsets: exclusive sums over the regions before this one
   uint32_t p_off = 0, g_off = 0, ht_off = 0;
   for (uint32_t q = 0; q < r; ++q) {
@@ -522,14 +579,10 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     h[H_HTMASK] = slots - 1;
     h[H_W2] = w2;
     h[H_W1] = w1;
-    s_goff[r] = g_off;
   }
-  __syncthreads();
-  // iteration order of the eight code maps: eight lanes of one wave replay libstdc++ side by side
-  if (threadIdx.x < p.nreg) {
-    const uint32_t q = threadIdx.x;
-    umap_order_seq(hg[q], s_g[q], nxt[q], bkt[q], pool + kpm_off_giter(p.kmax) + s_goff[q]);
-  }
+  // iteration order of this region's code map, wave-parallel
+  umap_order_par<64>(hg[r], G, okeys[r], seq_a[r], seq_b[r], bmin[r], WaveBarrier{},
+                     pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
 // ---- matching --------------------------------------------------------------------------------------
@@ -563,14 +616,15 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
 // Two instances: SMALL (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
 // LDS, ~20 waves per CU) runs first on every (pair, region) and leaves the marker
-// the item in the work list when a limit is hit; the LARGE instance (2048 / 1024 / 1024)
+// the item in the work list when a limit is hit; the LARGE instance (4096 / 2048 / 2048)
 // then redoes exactly those.
 template <bool SMALL, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
   __shared__ uint32_t mg_p[KM_MG], mg_c[KM_MG], mg_base[KM_MG + 1];
   __shared__ uint64_t hh[KM_DMAX];
-  __shared__ uint16_t nxt[KM_DMAX], bkt[KM_BK + 3], pos_of[KM_DMAX];
+  __shared__ uint16_t seq_a[KM_DMAX], seq_b[KM_DMAX], pos_of[KM_DMAX];
+  __shared__ uint32_t okeys[KM_DMAX], bmin[KM_BK];
   __shared__ uint64_t skey[KM_DMAX];
 
   const uint32_t lane = threadIdx.x;
@@ -789,10 +843,8 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  if (lane == 0) {
-    // order[k] = insertion index of the k-th iterated offset, written into nxt-sized scratch
-    umap_order_seq(hh, nd, nxt, bkt, pos_of);
-  }
+  // pos_of[k] = insertion index of the k-th iterated offset
+  umap_order_par<64>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // pos_of[k] = insertion index at iteration position k; pick the best three by

@@ -7,7 +7,7 @@
 //     offset = previous - current and marks the cell (min(px,cx)/cw, min(py,cy)/ch);
 //   find_best (kpm.hpp:281-298): the offset with most votes — the FIRST such offset in the
 //     iteration order of the std::unordered_map<offset, ...> totalizator on ties, which is
-//     replayed with umap_order_seq exactly as in kpm_match;
+//     replayed with umap_order_par exactly as in kpm_match;
 //   count_active_cells / filter_keypoints (kpm.hpp:302-367): distinct cells of the current
 //     keypoints inside the overlap whose translated position is covered by the previous mask;
 //   accept unless matched_cells < active * 0.66f (kpm.hpp:388) — the path's only fp32 op,
@@ -38,7 +38,8 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
   __shared__ unsigned long long pc[KC_PS];                             // (offset slot + 1) << 32 | cell key
   __shared__ uint32_t mg_p[KC_MG], mg_c[KC_MG], mg_base[KC_MG + 1];
   __shared__ uint64_t hh[KC_DMAX], skey[KC_DMAX];
-  __shared__ uint16_t nxt[KC_DMAX], bkt[1109 + 3], pos_of[KC_DMAX];
+  __shared__ uint16_t seq_a[KC_DMAX], seq_b[KC_DMAX], pos_of[KC_DMAX];
+  __shared__ uint32_t okeys[KC_DMAX], bmin[1109];
 
   const uint32_t lane = threadIdx.x;
   const uint32_t q = blockIdx.x;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane == 0) umap_order_seq(hh, nd, nxt, bkt, pos_of);
+    umap_order_par<64>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     uint32_t first = 0xffffffffu;  // smallest iteration position holding cmax votes
