@@ -317,7 +317,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
-  if (needs_large && !needs_large[fslot]) return;  // built by kpm_build_small (uniform)
+  if (needs_large && needs_large[fslot] != 2u) return;  // built by the wave-per-region kernels (uniform)
   uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
   uint32_t* hdr = pool;
   uint32_t* pts = pool + kpm_off_pts(p.kmax);
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   }
   __syncthreads();
   if (s_big) {  // uniform for the block
-    if (threadIdx.x == 0) needs_large[fslot] = 1u;
+    if (threadIdx.x == 0) needs_large[fslot] = k > 2048 ? 2u : 1u;  // tier: medium (1) or general (2)
     return;
   }
   if (threadIdx.x == 0) needs_large[fslot] = 0u;
@@ -585,6 +585,183 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
                      pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
+// ---- medium frames: one wave per region, up to 256 entries per region ---------------------------------
+// Same division of labour as kpm_build_small (wave r owns region r, no block barriers inside
+// the region work) for the frames that kernel passed on (tier 1): a region's entries are
+// walked 64 at a time, the sort runs in the wave's LDS slice.  Frames with a bigger region
+// go on to the general instance (tier 2).
+constexpr uint32_t KM_RC = 256;
+
+__device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint32_t* total) {
+  uint32_t incl = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  *total = (uint32_t)__shfl((int)incl, 63);
+  return incl - v;
+}
+
+__global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier) {
+  __shared__ uint16_t ent[8][KM_RC], slot_of[8][KM_RC], gid_of[8][KM_RC], seq_a[8][KM_RC], seq_b[8][KM_RC];
+  __shared__ uint32_t htl[8][2 * KM_RC], keys[8][KM_RC], bmin[8][257];
+  __shared__ uint64_t hg[8][KM_RC];
+  __shared__ uint32_t s_e[8], s_g[8];
+  __shared__ uint32_t s_big;
+
+  const uint32_t fslot = blockIdx.x;
+  if (tier[fslot] != 1u) return;  // uniform: built already, or not yet examined
+  const bool is_halo = fslot == p.n;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
+  if (k > p.kmax) k = p.kmax;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t EMPTY = 0xffffffffu;
+  const WaveBarrier wbar{};
+  if (threadIdx.x == 0) s_big = 0u;
+  __syncthreads();
+  const bool mine = r < p.nreg;
+  // 1. region entries in scan order
+  uint32_t e = 0;
+  if (mine) {
+    for (uint32_t base = 0; base < k; base += 64) {
+      uint32_t i = base + lane;
+      bool in = i < k && ((desc[i].region_mask >> r) & 1u);
+      uint64_t bal = __builtin_amdgcn_ballot_w64(in);
+      uint32_t pos = e + mbcnt(bal);
+      if (in && pos < KM_RC) ent[r][pos] = (uint16_t)i;
+      e += (uint32_t)__builtin_popcountll(bal);
+    }
+    if (e > KM_RC && lane == 0) atomicOr(&s_big, 1u);
+  }
+  __syncthreads();
+  if (s_big) {
+    if (threadIdx.x == 0) tier[fslot] = 2u;
+    return;
+  }
+  if (threadIdx.x == 0) tier[fslot] = 0u;
+  uint32_t slots = 16, G = 0, w2 = 0, w1 = 0;
+  if (mine) {
+    // 2. group by code
+    while (slots < 2 * e) slots <<= 1;
+    const uint32_t mask = slots - 1;
+    for (uint32_t s = lane; s < slots; s += 64) htl[r][s] = EMPTY;
+    wbar();
+    for (uint32_t i = lane; i < e; i += 64) {
+      uint32_t c[4];
+      load_code(desc + ent[r][i], c);
+      const uint32_t wgt = c[3] & 0xfu;
+      w2 += wgt == 2u;
+      w1 += wgt == 1u;
+      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      for (;;) {
+        uint32_t v = atomicCAS(&htl[r][s], EMPTY, i);
+        if (v == EMPTY) break;
+        uint32_t c2[4];
+        load_code(desc + ent[r][v], c2);
+        if (same_code(c, c2)) {
+          atomicMin(&htl[r][s], i);
+          break;
+        }
+        s = (s + 1) & mask;
+      }
+      slot_of[r][i] = (uint16_t)s;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      w2 += (uint32_t)__shfl_xor((int)w2, o);
+      w1 += (uint32_t)__shfl_xor((int)w1, o);
+    }
+    wbar();
+    // 3. order entries by (first occurrence of their code, scan order)
+    uint32_t n2 = 1;
+    while (n2 < e) n2 <<= 1;
+    for (uint32_t i = lane; i < n2; i += 64) keys[r][i] = i < e ? (htl[r][slot_of[r][i]] << 16 | i) : 0xffffffffu;
+    for (uint32_t kk = 2; kk <= n2; kk <<= 1)
+      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+        wbar();
+        for (uint32_t i = lane; i < n2; i += 64) {
+          const uint32_t ixj = i ^ j;
+          if (ixj > i) {
+            const uint32_t x = keys[r][i], y = keys[r][ixj];
+            if ((x > y) == ((i & kk) == 0)) {
+              keys[r][i] = y;
+              keys[r][ixj] = x;
+            }
+          }
+        }
+      }
+    wbar();
+    // 4. number the groups (first-occurrence order)
+    for (uint32_t base = 0; base < e; base += 64) {
+      const uint32_t j = base + lane;
+      const bool st = j < e && (j == 0 || (keys[r][j] >> 16) != (keys[r][j - 1] >> 16));
+      const uint64_t sb = __builtin_amdgcn_ballot_w64(st);
+      if (st) {
+        const uint32_t gid = G + mbcnt(sb), first = keys[r][j] >> 16;
+        gid_of[r][first] = (uint16_t)gid;
+        uint32_t cf[4];
+        load_code(desc + ent[r][first], cf);
+        hg[r][gid] = fnv_code(cf);
+      }
+      G += (uint32_t)__builtin_popcountll(sb);
+    }
+    if (lane == 0) {
+      s_e[r] = e;
+      s_g[r] = G;
+    }
+  } else if (lane == 0 && r < 8) {
+    s_e[r] = 0;
+    s_g[r] = 0;
+  }
+  __syncthreads();
+  if (!mine) return;
+  uint32_t p_off = 0, g_off = 0, ht_off = 0;
+  for (uint32_t q = 0; q < r; ++q) {
+    p_off += s_e[q];
+    g_off += s_g[q];
+    uint32_t sl = 16;
+    while (sl < 2 * s_e[q]) sl <<= 1;
+    ht_off += sl;
+  }
+  uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
+  uint32_t* pts = pool + kpm_off_pts(p.kmax);
+  uint32_t* gstart = pool + kpm_off_gstart(p.kmax);
+  uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
+  uint32_t* ght = pool + kpm_off_ht(p.kmax);
+  for (uint32_t j = lane; j < e; j += 64) {
+    const uint32_t first = keys[r][j] >> 16, i = keys[r][j] & 0xffffu;
+    const rmx_desc* d = desc + ent[r][i];
+    pts[p_off + j] = (uint32_t)d->x | (uint32_t)d->y << 16;
+    if (j == 0 || first != (keys[r][j - 1] >> 16)) {
+      const uint32_t gid = gid_of[r][first];
+      gstart[g_off + r + gid] = p_off + j;
+      gfirst[g_off + gid] = ent[r][first];
+    }
+  }
+  for (uint32_t sidx = lane; sidx < slots; sidx += 64) {
+    const uint32_t v = htl[r][sidx];
+    ght[ht_off + sidx] = v == EMPTY ? 0u : (uint32_t)gid_of[r][v] + 1u;
+  }
+  if (lane == 0) {
+    gstart[g_off + r + G] = p_off + e;
+    uint32_t* h = pool + r * 8;
+    h[H_E] = e;
+    h[H_G] = G;
+    h[H_POFF] = p_off;
+    h[H_GOFF] = g_off;
+    h[H_HTOFF] = ht_off;
+    h[H_HTMASK] = slots - 1;
+    h[H_W2] = w2;
+    h[H_W1] = w1;
+  }
+  wbar();
+  // keys[r] is free again: iteration order of this region's code map
+  umap_order_par<64>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
+}
+
 // ---- matching --------------------------------------------------------------------------------------
 
 struct KpmMatchParams {
@@ -592,7 +769,8 @@ struct KpmMatchParams {
   const rmx_desc* halo_desc;
   const uint32_t* pool;
   uint32_t* tickets;  // pairs x nreg x 3 x {key, count}
-  uint32_t* work;     // [0] = count, [1..] = (pair * nreg + region) items left to the large instance
+  uint32_t* work_in;   // [0] = count, [1..] = (pair * nreg + region) items passed on by the tier below
+  uint32_t* work_out;  // same layout: items this tier passes on
   uint32_t* status;
   uint32_t n, kmax, nreg;
   uint32_t has_halo;
@@ -614,11 +792,12 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
 
 // One wave per (pair, region).  Pair index q: current frame = q (q = 0 pairs the halo with
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
-// Two instances: SMALL (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
-// LDS, ~20 waves per CU) runs first on every (pair, region) and leaves the marker
-// the item in the work list when a limit is hit; the LARGE instance (4096 / 2048 / 2048)
-// then redoes exactly those.
-template <bool SMALL, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
+// Three instances.  TIER 0 (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
+// LDS, ~20 waves per CU) runs first on every (pair, region) and appends the item to its
+// output work list when a limit is hit; TIER 1 (1024 / 256 / 512, 30 KB) redoes exactly
+// those and passes what it cannot hold to TIER 2 (4096 / 2048 / 2048, 136 KB: one wave
+// per CU), which flags the status word instead.
+template <int TIER, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
   __shared__ uint32_t mg_p[KM_MG], mg_c[KM_MG], mg_base[KM_MG + 1];
@@ -628,11 +807,12 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint64_t skey[KM_DMAX];
 
   const uint32_t lane = threadIdx.x;
-  // SMALL: one (pair, region) per workgroup.  LARGE: a fixed grid walks the work list the
-  // small instance appended to (no launch of n*8 mostly empty workgroups).
-  const uint32_t it_end = SMALL ? blockIdx.x + 1 : p.work[0];
+  // TIER 0: one (pair, region) per workgroup.  Above: a fixed grid walks the work list the
+  // tier below appended to (no launch of n*8 mostly empty workgroups).
+  constexpr bool SMALL = TIER == 0;
+  const uint32_t it_end = SMALL ? blockIdx.x + 1 : p.work_in[0];
   for (uint32_t it = blockIdx.x; it < it_end; it += gridDim.x) {
-  const uint32_t item = SMALL ? it : p.work[1 + it];
+  const uint32_t item = SMALL ? it : p.work_in[1 + it];
   const uint32_t q = item / p.nreg, r = item % p.nreg;
   uint32_t* ticket = p.tickets + ((size_t)q * p.nreg + r) * 6;
   __builtin_amdgcn_wave_barrier();
@@ -708,8 +888,8 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   }
   if (overflow) {
     if (lane == 0) {
-      if (SMALL)
-        p.work[1 + atomicAdd(&p.work[0], 1u)] = item;
+      if (TIER < 2)
+        p.work_out[1 + atomicAdd(&p.work_out[0], 1u)] = item;
       else
         atomicOr(&p.status[1], 2u);
     }
@@ -761,8 +941,8 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   for (int o = 32; o > 0; o >>= 1) D += (uint32_t)__shfl_xor((int)D, o);
   if (D > KM_DMAX) {
     if (lane == 0) {
-      if (SMALL)
-        p.work[1 + atomicAdd(&p.work[0], 1u)] = item;
+      if (TIER < 2)
+        p.work_out[1 + atomicAdd(&p.work_out[0], 1u)] = item;
       else
         atomicOr(&p.status[1], 4u);
     }
