@@ -34,6 +34,11 @@ struct rmx_ctx {
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
+  // status words as read back by the last rmx_frc_scan (which synchronises anyway); valid
+  // until the next call that can raise them — saves two host round trips per step
+  uint32_t* host_words = nullptr;  // pinned, 16 words
+  uint32_t cached_status[2] = {0, 0};
+  bool status_cached = false;
   KpmWorkspace kpm{};
   uint32_t* blit_ws = nullptr;  // fgm_blit binning workspace
   size_t blit_ws_bytes = 0;
@@ -169,7 +174,9 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
-      hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess) {
+      hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
+      hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
+    if (ctx->status) (void)hipFree(ctx->status);
     delete ctx;
     return RMX_ERR_DEVICE;
   }
@@ -185,6 +192,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->status) (void)hipFree(ctx->status);
+  if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
@@ -298,6 +306,7 @@ int rmx_memset(rmx_ctx* ctx, void* dst, int value, size_t bytes) {
 int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* median, rmx_desc* desc,
                   uint32_t* kcount) {
   if (!ctx || !frames || !median || !desc || !kcount || n == 0 || n > 0x0fffffffu) return RMX_ERR_ARG;
+  ctx->status_cached = false;
   RMX_HIP(hipSetDevice(ctx->device));
   if (int rc = ensure_workspace(ctx, n)) return rc;
   ctx->n_last = n;
@@ -369,8 +378,14 @@ int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k) {
   if (!ctx) return RMX_ERR_ARG;
   RMX_HIP(hipSetDevice(ctx->device));
   uint32_t st = 0;
-  RMX_HIP(hipMemcpyAsync(&st, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-  RMX_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->status_cached && !max_k) {
+    st = ctx->cached_status[0];
+    ctx->cached_status[0] = 0;
+  } else {
+    RMX_HIP(hipMemcpyAsync(ctx->host_words, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    RMX_HIP(hipStreamSynchronize(ctx->stream));
+    st = ctx->host_words[0];
+  }
   if (max_k) {  // diagnostic: the per-frame counts are only fetched when asked for
     *max_k = 0;
     if (ctx->n_last) {

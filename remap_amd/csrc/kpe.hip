@@ -241,12 +241,11 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
 // ---- kernel 2: finish the candidates ---------------------------------------------------------------
 // compute_pixel's second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379).
 // A candidate's data moves in two phases so that several candidates per lane can be in
-// flight: gather (11 loads from L2 / Infinity Cache: kpe_main just streamed these lines)
+// flight: gather (10 loads from L2 / Infinity Cache: kpe_main just streamed these lines)
 // and resolve (rank 12 of 25 by a 4-step binary search with SWAR byte compares counted by
 // v_sad_u8, weight, code bytes, append).
 struct CandData {
   uint32_t lo[5], hi[5];
-  uint32_t med;
 };
 
 __device__ __forceinline__ void gather_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, CandData& d) {
@@ -258,7 +257,6 @@ __device__ __forceinline__ void gather_candidate(const KpeParams& p, uint32_t x,
     d.lo[r] = v.x;
     d.hi[r] = v.y;
   }
-  d.med = p.median[fo + (size_t)y * p.W + x];
 }
 
 __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool active,
@@ -277,8 +275,21 @@ __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x
   v[5] = map_ord(e[0] | e[1] << 8 | e[2] << 16 | e[3] << 24) | 0x80808080u;
   v[6] = map_ord(e[4]) | 0x80808080u;  // unused bytes hold rank 0: never >= a threshold >= 1
   const uint32_t p1 = (v[2] >> 16) & 0xfu;
-  // p3 = rank of the median kpe_main stored for this pixel (kpe.hpp:313-314)
-  const uint32_t p3 = map_ord(d.med & 0xfu) & 0xfu;
+  // p3 = 4th largest of the inner 3x3 (kpe.hpp:313-314), recomputed from the window already
+  // gathered: cheaper than touching the median plane's line for one byte
+  uint32_t p3 = 0;
+  {
+    const uint32_t m1 = (v[1] & 0xffffff00u) | 0x80u, m2 = (v[2] & 0xffffff00u) | 0x80u,
+                   m3 = (v[3] & 0xffffff00u) | 0x80u;
+#pragma unroll
+    for (uint32_t bit = 8; bit; bit >>= 1) {
+      const uint32_t c = p3 | bit, T = c * 0x01010101u;
+      uint32_t acc = __builtin_amdgcn_sad_u8((m1 - T) & 0x80808080u, 0u, 0u);
+      acc = __builtin_amdgcn_sad_u8((m2 - T) & 0x80808080u, 0u, acc);
+      acc = __builtin_amdgcn_sad_u8((m3 - T) & 0x80808080u, 0u, acc);
+      if ((acc >> 7) >= 4u) p3 = c;
+    }
+  }
   // largest t with #(rank >= t) >= 12  ==  first bin from the top whose running total
   // reaches 12 (kpe.hpp:326-340)
   uint32_t t = 0;

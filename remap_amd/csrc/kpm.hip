@@ -212,12 +212,24 @@ struct KpmWorkspace {
   uint32_t n_cap = 0, kmax = 0;
   size_t bytes = 0;
 };
-__host__ __device__ inline uint32_t kpm_stride_u32(uint32_t kmax) { return HDR_U32 + 4 * kmax * 4 + 8 + 16 * kmax + 128; }
+__host__ __device__ inline uint32_t kpm_stride_u32(uint32_t kmax) { return HDR_U32 + 48 * kmax + 136; }
 __host__ __device__ inline uint32_t kpm_off_pts(uint32_t) { return HDR_U32; }
 __host__ __device__ inline uint32_t kpm_off_gstart(uint32_t kmax) { return HDR_U32 + 4 * kmax; }
 __host__ __device__ inline uint32_t kpm_off_gfirst(uint32_t kmax) { return HDR_U32 + 8 * kmax + 8; }
 __host__ __device__ inline uint32_t kpm_off_giter(uint32_t kmax) { return HDR_U32 + 12 * kmax + 8; }
 __host__ __device__ inline uint32_t kpm_off_ht(uint32_t kmax) { return HDR_U32 + 16 * kmax + 8; }
+// 16-byte code of every group (by group id): saves the matcher the gfirst -> descriptor-row hops
+__host__ __device__ inline uint32_t kpm_off_gcode(uint32_t kmax) { return HDR_U32 + 32 * kmax + 136; }
+__device__ __forceinline__ void store_gcode(uint32_t* pool, uint32_t kmax, uint32_t g, const uint32_t c[4]) {
+  reinterpret_cast<uint4*>(pool + kpm_off_gcode(kmax))[g] = make_uint4(c[0], c[1], c[2], c[3]);
+}
+__device__ __forceinline__ void load_gcode(const uint32_t* pool, uint32_t kmax, uint32_t g, uint32_t c[4]) {
+  const uint4 v = reinterpret_cast<const uint4*>(pool + kpm_off_gcode(kmax))[g];
+  c[0] = v.x;
+  c[1] = v.y;
+  c[2] = v.z;
+  c[3] = v.w;
+}
 
 inline size_t kpm_workspace_bytes(const KpmWorkspace& w) { return w.bytes; }
 inline void kpm_workspace_free(KpmWorkspace& w) {
@@ -399,6 +411,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
         uint32_t c[4];
         load_code(desc + ent[first], c);
         hg[gid] = fnv_code(c);
+        store_gcode(pool, p.kmax, g_off + gid, c);
         ++gid;
       }
     }
@@ -558,6 +571,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
       uint32_t cf[4];
       load_code(desc + ent[r][first], cf);
       hg[r][gid] = fnv_code(cf);
+      store_gcode(pool, p.kmax, g_off + gid, cf);
       gid_of[r][first] = (uint16_t)gid;  // rank of a group's first entry -> group id
     }
   }
@@ -739,6 +753,9 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
       const uint32_t gid = gid_of[r][first];
       gstart[g_off + r + gid] = p_off + j;
       gfirst[g_off + gid] = ent[r][first];
+      uint32_t cf[4];
+      load_code(d, cf);  // j is the group's first entry
+      store_gcode(pool, p.kmax, g_off + gid, cf);
     }
   }
   for (uint32_t sidx = lane; sidx < slots; sidx += 64) {
@@ -848,14 +865,14 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
     if (base + lane < Gc) {
       gc = c_giter[base + lane];
       uint32_t c[4];
-      load_code(cdesc + c_gfirst[gc], c);
+      load_gcode(Cc, p.kmax, ch[H_GOFF] + gc, c);
       if (use_all || (c[3] & 0xfu) == 2u) {
         uint32_t s = (uint32_t)fnv_code(c) & pmask;
         for (;;) {
           uint32_t v = p_ht[s];
           if (v == 0) break;
           uint32_t c2[4];
-          load_code(pdesc + p_gfirst[v - 1], c2);
+          load_gcode(P, p.kmax, ph[H_GOFF] + v - 1, c2);
           if (same_code(c, c2)) {
             gp = v - 1;
             pairs = (p_gstart[gp + 1] - p_gstart[gp]) * (c_gstart[gc + 1] - c_gstart[gc]);
