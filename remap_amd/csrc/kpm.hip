@@ -807,6 +807,80 @@ __device__ __forceinline__ uint64_t wave_max_u64(uint64_t v) {
   return v;
 }
 
+// top_offsets(total, 3) with ties (kpm.hpp:127-159): by count, ties by iteration order of the
+// totalizator map.  Insertion order of the totalizator = order of first touch among the
+// pairs (hs).  One wave; scratch sized for the distinct offsets the table can hold.
+template <uint32_t HSLOTS>
+__device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const uint32_t* hs, uint64_t* skey, uint64_t* hh,
+                                  uint32_t* okeys, uint16_t* seq_a, uint16_t* seq_b, uint16_t* pos_of, uint32_t* bmin,
+                                  uint32_t* ticket, uint32_t lane) {
+  // exact path: insertion order of the totalizator = order of first occurrence among pairs
+  // compact distinct offsets
+  uint32_t nd = 0;
+  for (uint32_t i = 0; i < HSLOTS; i += 64) {
+    uint32_t s = i + lane;
+    bool occ = hk[s] != 0;
+    uint64_t bal = __builtin_amdgcn_ballot_w64(occ);
+    if (occ) skey[nd + mbcnt(bal)] = (uint64_t)hs[s] << 32 | s;
+    nd += (uint32_t)__builtin_popcountll(bal);
+  }
+  uint32_t n2 = 1;
+  while (n2 < nd) n2 <<= 1;
+  for (uint32_t i = nd + lane; i < n2; i += 64) skey[i] = ~0ull;
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      for (uint32_t i = lane; i < n2; i += 64) {
+        uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          uint64_t x = skey[i], y = skey[ixj];
+          bool up = (i & k) == 0;
+          if ((x > y) == up) {
+            skey[i] = y;
+            skey[ixj] = x;
+          }
+        }
+      }
+    }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  for (uint32_t i = lane; i < nd; i += 64) {
+    uint32_t s = (uint32_t)skey[i];
+    uint32_t key = hk[s];
+    hh[i] = fnv_offset((int32_t)(key >> 16) - 32768, (int32_t)(key & 0xffffu) - 32768);
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // pos_of[k] = insertion index of the k-th iterated offset
+  umap_order_par<64>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+  // pos_of[k] = insertion index at iteration position k; pick the best three by
+  // (count desc, iteration position asc)
+  uint32_t sel_pos[3];
+  for (int rdx = 0; rdx < 3; ++rdx) {
+    uint64_t m = 0;
+    for (uint32_t kpos = lane; kpos < nd; kpos += 64) {
+      bool used = false;
+      for (int u = 0; u < rdx; ++u) used |= sel_pos[u] == kpos;
+      if (!used) {
+        uint32_t s = (uint32_t)skey[pos_of[kpos]];
+        uint64_t cand = (uint64_t)hc[s] << 32 | (uint64_t)(0xffffffffu - kpos);
+        m = cand > m ? cand : m;
+      }
+    }
+    uint64_t w = wave_max_u64(m);
+    sel_pos[rdx] = w ? 0xffffffffu - (uint32_t)w : 0xffffffffu;
+    if (w != 0 && lane == 0) {
+      uint32_t s = (uint32_t)skey[pos_of[sel_pos[rdx]]];
+      ticket[2 * rdx] = hk[s];
+      ticket[2 * rdx + 1] = hc[s];
+    }
+  }
+}
+
 // One wave per (pair, region).  Pair index q: current frame = q (q = 0 pairs the halo with
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
 // Three instances.  TIER 0 (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
@@ -826,10 +900,9 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   const uint32_t lane = threadIdx.x;
   // TIER 0: one (pair, region) per workgroup.  Above: a fixed grid walks the work list the
   // tier below appended to (no launch of n*8 mostly empty workgroups).
-  constexpr bool SMALL = TIER == 0;
-  const uint32_t it_end = SMALL ? blockIdx.x + 1 : p.work_in[0];
+  const uint32_t it_end = p.work_in[0];
   for (uint32_t it = blockIdx.x; it < it_end; it += gridDim.x) {
-  const uint32_t item = SMALL ? it : p.work_in[1 + it];
+  const uint32_t item = p.work_in[1 + it];
   const uint32_t q = item / p.nreg, r = item % p.nreg;
   uint32_t* ticket = p.tickets + ((size_t)q * p.nreg + r) * 6;
   __builtin_amdgcn_wave_barrier();
@@ -993,6 +1066,18 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   const uint32_t c1 = (uint32_t)(best[0] >> 32), c2 = (uint32_t)(best[1] >> 32), c3 = (uint32_t)(best[2] >> 32),
                  c4 = (uint32_t)(best[3] >> 32);
   const bool tie = (D >= 2 && c1 == c2) || (D >= 3 && c2 == c3) || (D >= 4 && c3 == c4);
+#ifdef RMX_STATS
+  if (lane == 0) {
+    atomicAdd(&p.status[16 + TIER * 8], 1u);
+    if (tie) atomicAdd(&p.status[17 + TIER * 8], 1u);
+    atomicAdd(&p.status[18 + TIER * 8], D);
+    atomicAdd(&p.status[19 + TIER * 8], total);
+    atomicAdd(&p.status[20 + TIER * 8], nm);
+    if (tie && D > 13) atomicAdd(&p.status[21 + TIER * 8], 1u);
+    if (tie && D > 29) atomicAdd(&p.status[22 + TIER * 8], 1u);
+    if (tie && D > 59) atomicAdd(&p.status[23 + TIER * 8], 1u);
+  }
+#endif
   if (!tie) {
     if (lane < 3 && lane < D) {
       uint32_t s = 0xffffffffu - (uint32_t)best[lane];
@@ -1001,72 +1086,228 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
     }
     continue;
   }
-  // exact path: insertion order of the totalizator = order of first occurrence among pairs
-  // compact distinct offsets
-  uint32_t nd = 0;
-  for (uint32_t i = 0; i < KM_HSLOTS; i += 64) {
-    uint32_t s = i + lane;
-    bool occ = hk[s] != 0;
-    uint64_t bal = __builtin_amdgcn_ballot_w64(occ);
-    if (occ) skey[nd + mbcnt(bal)] = (uint64_t)hs[s] << 32 | s;
-    nd += (uint32_t)__builtin_popcountll(bal);
+  exact_top3<KM_HSLOTS>(hk, hc, hs, skey, hh, okeys, seq_a, seq_b, pos_of, bmin, ticket, lane);
+  }  // work items
+}
+
+// ---- pair-wave instance: ONE wave handles all eight regions of a (previous, current) pair --------------
+// On the sparse stream a region holds ~10 codes and ~10 point pairs, so a wave per (pair,
+// region) idles 50+ lanes and the 8x larger grid is pure launch/latency cost.  Here the lanes
+// run over the concatenated code lists of the eight regions; every region has its own
+// 64-slot offset table.  A pair with more than PW_MG codes, or a region with more than
+// PW_DMAX distinct offsets, is passed on to the per-(pair, region) instances via the work list.
+constexpr uint32_t PW_MG = 256, PW_SLOTS = 64, PW_DMAX = 32;
+
+__device__ __forceinline__ void push_items(uint32_t* work, bool mine, uint32_t item, uint32_t lane) {
+  const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
+  if (bal == 0) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(&work[0], (uint32_t)__builtin_popcountll(bal));
+  base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+  if (mine) work[1 + base + mbcnt(bal)] = item;
+}
+
+__global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
+  __shared__ uint32_t hk[8 * PW_SLOTS], hc[8 * PW_SLOTS], hs[8 * PW_SLOTS];
+  __shared__ uint32_t mg_p[PW_MG], mg_c[PW_MG], mg_n[PW_MG], mg_base[PW_MG + 1];
+  __shared__ uint64_t skey[PW_SLOTS], hh[PW_SLOTS];
+  __shared__ uint16_t seq_a[PW_SLOTS], seq_b[PW_SLOTS], pos_of[PW_SLOTS];
+  __shared__ uint32_t okeys[PW_SLOTS], bmin[64];
+
+  const uint32_t lane = threadIdx.x, q = blockIdx.x;
+  uint32_t* tick = p.tickets + (size_t)q * 48;
+  if (lane < 48) tick[lane] = 0;
+  if (q == 0 && !p.has_halo) return;
+  const uint32_t stride = kpm_stride_u32(p.kmax);
+  const uint32_t* P = p.pool + (size_t)(q == 0 ? p.n : q - 1) * stride;
+  const uint32_t* Cc = p.pool + (size_t)q * stride;
+  const uint32_t hp = P[lane], hcu = Cc[lane];  // header word: region lane >> 3, field lane & 7
+  // code-list prefix over the regions that can produce a ticket (both maps non-empty)
+  uint32_t gpre[9];
+  gpre[0] = 0;
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t gc = (uint32_t)__builtin_amdgcn_readlane((int)hcu, r * 8 + H_G);
+    const uint32_t gp = (uint32_t)__builtin_amdgcn_readlane((int)hp, r * 8 + H_G);
+    gpre[r + 1] = gpre[r] + ((gc && gp) ? gc : 0u);
   }
-  uint32_t n2 = 1;
-  while (n2 < nd) n2 <<= 1;
-  for (uint32_t i = nd + lane; i < n2; i += 64) skey[i] = ~0ull;
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t k = 2; k <= n2; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-      __builtin_amdgcn_wave_barrier();
-      for (uint32_t i = lane; i < n2; i += 64) {
-        uint32_t ixj = i ^ j;
-        if (ixj > i) {
-          uint64_t x = skey[i], y = skey[ixj];
-          bool up = (i & k) == 0;
-          if ((x > y) == up) {
-            skey[i] = y;
-            skey[ixj] = x;
+  const uint32_t Gtot = gpre[8];
+  if (Gtot == 0) return;
+  {
+    const uint32_t my_gc = (uint32_t)__shfl((int)hcu, (int)((lane & 7u) * 8 + H_G));
+    const uint32_t my_gp = (uint32_t)__shfl((int)hp, (int)((lane & 7u) * 8 + H_G));
+    if (Gtot > PW_MG) {
+      push_items(p.work_out, lane < 8 && my_gc && my_gp, q * 8 + lane, lane);
+      return;
+    }
+  }
+  const uint32_t* c_giter = Cc + kpm_off_giter(p.kmax);
+  const uint32_t* c_gstart = Cc + kpm_off_gstart(p.kmax);
+  const uint32_t* p_gstart = P + kpm_off_gstart(p.kmax);
+  const uint32_t* p_ht = P + kpm_off_ht(p.kmax);
+  const uint32_t* c_pts = Cc + kpm_off_pts(p.kmax);
+  const uint32_t* p_pts = P + kpm_off_pts(p.kmax);
+
+  // ---- a. shared codes, region by region in each current map's iteration order ----
+  uint32_t nm = 0, total = 0;
+  for (uint32_t base = 0; base < Gtot; base += 64) {
+    const uint32_t k = min(base + lane, Gtot - 1);
+    uint32_t r = 0, jbase = 0;
+#pragma unroll
+    for (int q2 = 1; q2 < 8; ++q2)
+      if (k >= gpre[q2]) {
+        r = q2;
+        jbase = gpre[q2];
+      }
+    // (a region without codes has zero width, so the last boundary <= k names k's region)
+    const uint32_t goff_c = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_GOFF));
+    const uint32_t w2c = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_W2));
+    const uint32_t goff_p = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_GOFF));
+    const uint32_t htoff = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTOFF));
+    const uint32_t pmask = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTMASK));
+    const uint32_t w2p = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_W2));
+    uint32_t pairs = 0, ps = 0, cs = 0, nc = 0;
+    if (base + lane < Gtot) {
+      // kpm.hpp:219-222: all codes unless both regions are rich in weight-2 keypoints
+      const bool use_all = w2p < p.weight_switch || w2c <= p.weight_switch;
+      const uint32_t gc = c_giter[goff_c + (k - jbase)];
+      uint32_t c[4];
+      load_gcode(Cc, p.kmax, goff_c + gc, c);
+      if (use_all || (c[3] & 0xfu) == 2u) {
+        uint32_t s = (uint32_t)fnv_code(c) & pmask;
+        for (;;) {
+          const uint32_t v = p_ht[htoff + s];
+          if (v == 0) break;
+          uint32_t c2[4];
+          load_gcode(P, p.kmax, goff_p + v - 1, c2);
+          if (same_code(c, c2)) {
+            ps = p_gstart[goff_p + r + v - 1];
+            cs = c_gstart[goff_c + r + gc];
+            nc = c_gstart[goff_c + r + gc + 1] - cs;
+            pairs = (p_gstart[goff_p + r + v] - ps) * nc;
+            break;
           }
+          s = (s + 1) & pmask;
         }
       }
     }
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  for (uint32_t i = lane; i < nd; i += 64) {
-    uint32_t s = (uint32_t)skey[i];
-    uint32_t key = hk[s];
-    hh[i] = fnv_offset((int32_t)(key >> 16) - 32768, (int32_t)(key & 0xffffu) - 32768);
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(pairs != 0);
+    uint32_t incl = pairs;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= (uint32_t)o) incl += t;
+    }
+    if (pairs != 0) {
+      const uint32_t at = nm + mbcnt(bal);
+      mg_p[at] = ps;
+      mg_c[at] = cs | r << 20;
+      mg_n[at] = nc;
+      mg_base[at] = total + incl - pairs;
+    }
+    total += (uint32_t)__shfl((int)incl, 63);
+    nm += (uint32_t)__builtin_popcountll(bal);
   }
+  if (nm == 0) return;
+  if (lane == 0) mg_base[nm] = total;
+  for (uint32_t s = lane; s < 8 * PW_SLOTS; s += 64) {
+    hk[s] = 0;
+    hc[s] = 0;
+    hs[s] = 0xffffffffu;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- b. count_offsets: previous outer, current inner (kpm.hpp:94-95), one table per region ----
+  uint32_t fail = 0;
+  for (uint32_t t = lane; t < total; t += 64) {
+    uint32_t lo = 0, hi = nm;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (mg_base[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint32_t nc = mg_n[lo], rel = t - mg_base[lo], cw = mg_c[lo], r = cw >> 20;
+    const uint32_t ip = rel / nc, ic = rel - ip * nc;
+    const uint32_t pp = p_pts[mg_p[lo] + ip], cp = c_pts[(cw & 0xfffffu) + ic];
+    const int32_t dx = (int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu);
+    const int32_t dy = (int32_t)(pp >> 16) - (int32_t)(cp >> 16);
+    const uint32_t key = off_key(dx, dy), tb = r * PW_SLOTS;
+    uint32_t s = (key * 2654435761u) >> 26;
+    for (uint32_t probes = 0;; ++probes) {
+      const uint32_t v = atomicCAS(&hk[tb + s], 0u, key);
+      if (v == 0u || v == key) {
+        atomicAdd(&hc[tb + s], 1u);
+        atomicMin(&hs[tb + s], t);
+        break;
+      }
+      s = (s + 1) & (PW_SLOTS - 1);
+      if (probes >= PW_SLOTS) {
+        fail |= 1u << r;
+        break;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) fail |= (uint32_t)__shfl_xor((int)fail, o);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
-  // pos_of[k] = insertion index of the k-th iterated offset
-  umap_order_par<64>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-  // pos_of[k] = insertion index at iteration position k; pick the best three by
-  // (count desc, iteration position asc)
-  uint32_t sel_pos[3];
-  for (int rdx = 0; rdx < 3; ++rdx) {
+  const uint32_t rr = lane >> 3, sub = lane & 7u;
+  uint32_t D = 0;  // distinct offsets of region rr
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const uint32_t d = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hk[r * PW_SLOTS + lane] != 0));
+    if (d > PW_DMAX) fail |= 1u << r;
+    if (rr == (uint32_t)r) D = d;
+  }
+  push_items(p.work_out, lane < 8 && ((fail >> lane) & 1u), q * 8 + lane, lane);
+
+  // ---- c. top_offsets(total, 3), eight lanes per region ----
+  const bool okr = !((fail >> rr) & 1u) && D > 0;
+  const uint32_t tb = rr * PW_SLOTS;
+  uint64_t best[4];
+  uint32_t taken = 0;
+#pragma unroll
+  for (int rd = 0; rd < 4; ++rd) {
     uint64_t m = 0;
-    for (uint32_t kpos = lane; kpos < nd; kpos += 64) {
-      bool used = false;
-      for (int u = 0; u < rdx; ++u) used |= sel_pos[u] == kpos;
-      if (!used) {
-        uint32_t s = (uint32_t)skey[pos_of[kpos]];
-        uint64_t cand = (uint64_t)hc[s] << 32 | (uint64_t)(0xffffffffu - kpos);
+#pragma unroll
+    for (uint32_t i = 0; i < 8; ++i) {
+      const uint32_t s = sub * 8 + i;
+      if (hk[tb + s] != 0 && !((taken >> i) & 1u)) {
+        const uint64_t cand = (uint64_t)hc[tb + s] << 32 | (uint64_t)(0xffffffffu - s);
         m = cand > m ? cand : m;
       }
     }
-    uint64_t w = wave_max_u64(m);
-    sel_pos[rdx] = w ? 0xffffffffu - (uint32_t)w : 0xffffffffu;
-    if (w != 0 && lane == 0) {
-      uint32_t s = (uint32_t)skey[pos_of[sel_pos[rdx]]];
-      ticket[2 * rdx] = hk[s];
-      ticket[2 * rdx + 1] = hc[s];
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) {
+      const uint64_t t = (uint64_t)__shfl_xor((long long)m, o);
+      m = t > m ? t : m;
+    }
+    best[rd] = m;
+    if (m != 0) {
+      const uint32_t s = 0xffffffffu - (uint32_t)m;
+      if ((s >> 3) == sub) taken |= 1u << (s & 7u);
     }
   }
-  }  // work items
+  const uint32_t c1 = (uint32_t)(best[0] >> 32), c2 = (uint32_t)(best[1] >> 32), c3 = (uint32_t)(best[2] >> 32),
+                 c4 = (uint32_t)(best[3] >> 32);
+  const bool tie = (D >= 2 && c1 == c2) || (D >= 3 && c2 == c3) || (D >= 4 && c3 == c4);
+  if (okr && !tie && sub < 3 && sub < D) {
+    const uint32_t s = 0xffffffffu - (uint32_t)best[sub];
+    tick[rr * 6 + 2 * sub] = hk[tb + s];
+    tick[rr * 6 + 2 * sub + 1] = hc[tb + s];
+  }
+  uint64_t todo = __builtin_amdgcn_ballot_w64(okr && tie && sub == 0);
+  while (todo) {  // regions whose ticket depends on the totalizator's iteration order (uniform loop)
+    const uint32_t r = (uint32_t)__builtin_ctzll(todo) >> 3;
+    todo &= todo - 1;
+    exact_top3<PW_SLOTS>(hk + r * PW_SLOTS, hc + r * PW_SLOTS, hs + r * PW_SLOTS, skey, hh, okeys, seq_a, seq_b, pos_of,
+                         bmin, tick + r * 6, lane);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  }
 }
 
 struct KpmDeclareParams {

@@ -72,6 +72,23 @@ def test_kpm_repetitive_tiles_many_ties(gpu):
     check_seq(np.ascontiguousarray(frames))
 
 
+def test_kpm_sparse_frames_with_ambiguous_stamps(gpu):
+    # few keypoints per frame (the pair-wave instance), plus one identical 4x4 stamp at random
+    # places: code groups whose all-pairs offsets are mostly distinct -> equal counts inside
+    # a region (tie order of the totalizator); every 6th frame carries many stamps, more
+    # distinct offsets than the pair-wave tables hold (hand-over to the per-region tiers)
+    frames, _ = scroller_v1(36, dens=300)
+    frames = frames.copy()
+    rng = np.random.default_rng(5)
+    patch = rng.integers(0, 16, size=(4, 4), dtype=np.uint8)
+    for i in range(len(frames)):
+        for _ in range(int(rng.integers(2, 6)) if i % 6 else 14):
+            y, x = int(rng.integers(8, 224)), int(rng.integers(8, 306))
+            frames[i, y:y + 4, x:x + 4] = patch
+    g, ties = check_seq(frames)
+    assert ties > 10
+
+
 def test_kpm_breaks_and_blank_frames(gpu):
     frames, _ = scroller_v1(12, dens=100)
     frames = frames.copy()
