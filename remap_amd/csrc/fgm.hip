@@ -17,9 +17,21 @@ struct ScanParams {
   uint32_t first_is_start;
 };
 
+// Summary of a run of frames: did it contain a fragment start, the position offset since the
+// last start (or since the run's begin), and the number of starts.  Associative.
+struct ScanSeg {
+  int32_t r, x, y, c;
+};
+__device__ __forceinline__ ScanSeg seg_join(const ScanSeg& a, const ScanSeg& b) {  // a then b
+  return ScanSeg{a.r | b.r, b.r ? b.x : a.x + b.x, b.r ? b.y : a.y + b.y, a.c + b.c};
+}
+__device__ __forceinline__ ScanSeg seg_shfl_up(const ScanSeg& v, int o) {
+  return ScanSeg{__shfl_up(v.r, o), __shfl_up(v.x, o), __shfl_up(v.y, o), __shfl_up(v.c, o)};
+}
+
 __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
-  __shared__ int32_t s_reset[1024], s_dx[1024], s_dy[1024], s_cnt[1024];
-  const uint32_t tid = threadIdx.x;
+  __shared__ ScanSeg s_wave[16];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t chunk = (p.n + 1023) / 1024;
   const uint32_t i0 = min(p.n, tid * chunk), i1 = min(p.n, i0 + chunk);
   int32_t reset = 0, dx = 0, dy = 0, cnt = 0;
@@ -34,28 +46,31 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
       dy += p.dxdy[2 * i + 1];
     }
   }
-  s_reset[tid] = reset;
-  s_dx[tid] = dx;
-  s_dy[tid] = dy;
-  s_cnt[tid] = cnt;
+  // segmented scan of the 1024 chunk summaries: wave-inclusive by shuffles, the 16 wave
+  // totals by one thread, seeded with the carry
+  ScanSeg inc{reset, dx, dy, cnt};
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const ScanSeg t = seg_shfl_up(inc, o);
+    if (lane >= (uint32_t)o) inc = seg_join(t, inc);
+  }
+  if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
-  if (tid == 0) {  // exclusive scan of 1024 chunk summaries, seeded with the carry
-    int32_t ax = p.carry[0], ay = p.carry[1], ac = p.carry[2];
-    for (uint32_t t = 0; t < 1024; ++t) {
-      int32_t r = s_reset[t], x = s_dx[t], y = s_dy[t], c = s_cnt[t];
-      s_dx[t] = ax;
-      s_dy[t] = ay;
-      s_cnt[t] = ac;
-      ax = r ? x : ax + x;
-      ay = r ? y : ay + y;
-      ac += c;
+  if (tid == 0) {
+    ScanSeg acc{0, p.carry[0], p.carry[1], p.carry[2]};
+    for (uint32_t w = 0; w < 16; ++w) {
+      const ScanSeg t = s_wave[w];
+      s_wave[w] = acc;
+      acc = seg_join(acc, t);
     }
-    p.carry[0] = ax;
-    p.carry[1] = ay;
-    p.carry[2] = ac;
+    p.carry[0] = acc.x;
+    p.carry[1] = acc.y;
+    p.carry[2] = acc.c;
   }
   __syncthreads();
-  int32_t x = s_dx[tid], y = s_dy[tid], c = s_cnt[tid];
+  const ScanSeg before = seg_shfl_up(inc, 1);
+  const ScanSeg st = lane == 0 ? s_wave[wave] : seg_join(s_wave[wave], before);
+  int32_t x = st.x, y = st.y, c = st.c;
   for (uint32_t i = i0; i < i1; ++i) {
     bool start = (i == 0 && p.first_is_start);
     if (start || !p.matched[i]) {

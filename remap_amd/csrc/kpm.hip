@@ -158,6 +158,33 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
     bar();
     uint32_t n2 = 1;
     while (n2 < mk) n2 <<= 1;
+    if (NT == 64 && n2 <= 64) {
+      // a wave holds the whole level: sort in registers, one key per lane (ascending)
+      uint32_t key = 0xffffffffu;
+      if (tid < mk) {
+        const uint32_t e = tid < nk ? cur[tid] : tid;
+        key = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - tid);
+      }
+      for (uint32_t k = 2; k <= n2; k <<= 1)
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+          const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
+          const bool up = (tid & k) == 0, lower = (tid & j) == 0;
+          key = (lower == up) ? min(key, other) : max(key, other);
+        }
+      uint32_t v = 0;
+      if (tid < mk) {
+        const uint32_t t = 0xffffu - (key & 0xffffu);
+        v = t < nk ? cur[t] : t;
+      }
+      if (tid < mk) nxt[tid] = (uint16_t)v;
+      bar();
+      uint16_t* sw = cur;
+      cur = nxt;
+      nxt = sw;
+      nk = mk;
+      if (mk == n) break;
+      continue;
+    }
     for (uint32_t t = tid; t < n2; t += NT) {
       uint32_t key = 0xffffffffu;
       if (t < mk) {
