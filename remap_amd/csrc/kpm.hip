@@ -121,6 +121,42 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
   for (uint32_t p = head; p != NONE; p = next[p]) order[k++] = (OutT)p;
 }
 
+// Ascending bitonic sort of up to 256 keys held by ONE wave in registers: element i lives in
+// key[i >> 6] of lane i & 63.  Exchanges at distance < 64 are lane shuffles, larger ones stay
+// inside the lane.  n2 = power of two >= number of keys (unused elements = 0xffffffff).
+__device__ __forceinline__ void wave_sort4(uint32_t (&key)[4], uint32_t n2, uint32_t lane) {
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      if (j < 64) {
+        const bool lower = (lane & j) == 0;
+#pragma unroll
+        for (uint32_t s = 0; s < 4; ++s)
+          if (s * 64 < n2) {
+            const uint32_t other = (uint32_t)__shfl_xor((int)key[s], (int)j);
+            const bool up = ((s * 64 + lane) & k) == 0;
+            key[s] = (lower == up) ? min(key[s], other) : max(key[s], other);
+          }
+      } else {
+        // partner = same lane, slot s ^ (j >> 6): (0,1)(2,3) for j = 64, (0,2)(1,3) for j = 128
+        auto cx = [&](uint32_t& a, uint32_t& b, uint32_t s, uint32_t o) {
+          if (o * 64 < n2) {
+            const bool up = ((s * 64) & k) == 0;
+            const uint32_t lo = min(a, b), hi = max(a, b);
+            a = up ? lo : hi;
+            b = up ? hi : lo;
+          }
+        };
+        if (j == 64) {
+          cx(key[0], key[1], 0, 1);
+          cx(key[2], key[3], 2, 3);
+        } else {
+          cx(key[0], key[2], 0, 2);
+          cx(key[1], key[3], 1, 3);
+        }
+      }
+    }
+}
+
 // The same order without pointer chasing.  libstdc++ puts a node at the front of its bucket
 // and a new bucket at the front of the list, for inserts and for rehashes alike, so the list
 // after (re)building with B buckets from a sequence S is S sorted by (first position of the
@@ -159,7 +195,7 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
     uint32_t n2 = 1;
     while (n2 < mk) n2 <<= 1;
     if (NT == 64 && n2 <= 64) {
-      // a wave holds the whole level: sort in registers, one key per lane (ascending)
+      // one key per lane
       uint32_t key = 0xffffffffu;
       if (tid < mk) {
         const uint32_t e = tid < nk ? cur[tid] : tid;
@@ -171,12 +207,39 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
           const bool up = (tid & k) == 0, lower = (tid & j) == 0;
           key = (lower == up) ? min(key, other) : max(key, other);
         }
-      uint32_t v = 0;
       if (tid < mk) {
         const uint32_t t = 0xffffu - (key & 0xffffu);
-        v = t < nk ? cur[t] : t;
+        nxt[tid] = (uint16_t)(t < nk ? cur[t] : t);
       }
-      if (tid < mk) nxt[tid] = (uint16_t)v;
+      bar();
+      uint16_t* sw = cur;
+      cur = nxt;
+      nxt = sw;
+      nk = mk;
+      if (mk == n) break;
+      continue;
+    }
+    if (NT == 64 && n2 <= 256) {
+      // a wave holds the whole level: sort in registers (element t in key[t >> 6] of lane t & 63)
+      uint32_t key[4];
+#pragma unroll
+      for (uint32_t sl = 0; sl < 4; ++sl) {
+        const uint32_t t = sl * 64 + tid;
+        key[sl] = 0xffffffffu;
+        if (t < mk) {
+          const uint32_t e = t < nk ? cur[t] : t;
+          key[sl] = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
+        }
+      }
+      wave_sort4(key, n2, tid);
+#pragma unroll
+      for (uint32_t sl = 0; sl < 4; ++sl) {
+        const uint32_t j = sl * 64 + tid;
+        if (j < mk) {
+          const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
+          nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
+        }
+      }
       bar();
       uint16_t* sw = cur;
       cur = nxt;
@@ -719,21 +782,17 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
     // 3. order entries by (first occurrence of their code, scan order)
     uint32_t n2 = 1;
     while (n2 < e) n2 <<= 1;
-    for (uint32_t i = lane; i < n2; i += 64) keys[r][i] = i < e ? (htl[r][slot_of[r][i]] << 16 | i) : 0xffffffffu;
-    for (uint32_t kk = 2; kk <= n2; kk <<= 1)
-      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-        wbar();
-        for (uint32_t i = lane; i < n2; i += 64) {
-          const uint32_t ixj = i ^ j;
-          if (ixj > i) {
-            const uint32_t x = keys[r][i], y = keys[r][ixj];
-            if ((x > y) == ((i & kk) == 0)) {
-              keys[r][i] = y;
-              keys[r][ixj] = x;
-            }
-          }
-        }
+    {
+      uint32_t kreg[4];
+#pragma unroll
+      for (uint32_t sl = 0; sl < 4; ++sl) {
+        const uint32_t i = sl * 64 + lane;
+        kreg[sl] = i < e ? (htl[r][slot_of[r][i]] << 16 | i) : 0xffffffffu;
       }
+      wave_sort4(kreg, n2, lane);
+#pragma unroll
+      for (uint32_t sl = 0; sl < 4; ++sl) keys[r][sl * 64 + lane] = kreg[sl];
+    }
     wbar();
     // 4. number the groups (first-occurrence order)
     for (uint32_t base = 0; base < e; base += 64) {
