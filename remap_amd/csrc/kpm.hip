@@ -121,38 +121,41 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
   for (uint32_t p = head; p != NONE; p = next[p]) order[k++] = (OutT)p;
 }
 
-// Ascending bitonic sort of up to 256 keys held by ONE wave in registers: element i lives in
-// key[i >> 6] of lane i & 63.  Exchanges at distance < 64 are lane shuffles, larger ones stay
-// inside the lane.  n2 = power of two >= number of keys (unused elements = 0xffffffff).
-__device__ __forceinline__ void wave_sort4(uint32_t (&key)[4], uint32_t n2, uint32_t lane) {
+// Ascending bitonic sort of up to 64 * KPL keys held by ONE wave in registers: element i lives
+// in key[i >> 6] of lane i & 63.  Exchanges at distance < 64 are lane shuffles, larger ones
+// stay inside the lane.  n2 = power of two >= number of keys (unused elements = 0xffffffff).
+template <uint32_t KPL, uint32_t JS>
+__device__ __forceinline__ void wave_sort_inlane(uint32_t (&key)[KPL], uint32_t n2, uint32_t k) {
+#pragma unroll
+  for (uint32_t s = 0; s < KPL; ++s)
+    if ((s & JS) == 0 && (s | JS) < KPL && (s | JS) * 64 < n2) {
+      const bool up = ((s * 64) & k) == 0;
+      const uint32_t a = key[s], b = key[s | JS];
+      const uint32_t lo = min(a, b), hi = max(a, b);
+      key[s] = up ? lo : hi;
+      key[s | JS] = up ? hi : lo;
+    }
+}
+template <uint32_t KPL>
+__device__ __forceinline__ void wave_sort(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
+  static_assert(KPL == 4 || KPL == 8, "wave_sort: 4 or 8 keys per lane");
   for (uint32_t k = 2; k <= n2; k <<= 1)
     for (uint32_t j = k >> 1; j > 0; j >>= 1) {
       if (j < 64) {
         const bool lower = (lane & j) == 0;
 #pragma unroll
-        for (uint32_t s = 0; s < 4; ++s)
+        for (uint32_t s = 0; s < KPL; ++s)
           if (s * 64 < n2) {
             const uint32_t other = (uint32_t)__shfl_xor((int)key[s], (int)j);
             const bool up = ((s * 64 + lane) & k) == 0;
             key[s] = (lower == up) ? min(key[s], other) : max(key[s], other);
           }
+      } else if (j == 64) {
+        wave_sort_inlane<KPL, 1>(key, n2, k);
+      } else if (j == 128) {
+        wave_sort_inlane<KPL, 2>(key, n2, k);
       } else {
-        // partner = same lane, slot s ^ (j >> 6): (0,1)(2,3) for j = 64, (0,2)(1,3) for j = 128
-        auto cx = [&](uint32_t& a, uint32_t& b, uint32_t s, uint32_t o) {
-          if (o * 64 < n2) {
-            const bool up = ((s * 64) & k) == 0;
-            const uint32_t lo = min(a, b), hi = max(a, b);
-            a = up ? lo : hi;
-            b = up ? hi : lo;
-          }
-        };
-        if (j == 64) {
-          cx(key[0], key[1], 0, 1);
-          cx(key[2], key[3], 2, 3);
-        } else {
-          cx(key[0], key[2], 0, 2);
-          cx(key[1], key[3], 1, 3);
-        }
+        wave_sort_inlane<KPL, 4>(key, n2, k);
       }
     }
 }
@@ -177,7 +180,7 @@ struct BlockBarrier {
   __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
-template <uint32_t NT, typename Bar, typename OutT>
+template <uint32_t NT, uint32_t NMAX = 0xffffffffu, typename Bar, typename OutT>
 __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* keys, uint16_t* seq_a, uint16_t* seq_b,
                                       uint32_t* bmin, Bar bar, OutT* order, uint32_t tid) {
   uint16_t* cur = seq_a;
@@ -219,7 +222,7 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
       if (mk == n) break;
       continue;
     }
-    if (NT == 64 && n2 <= 256) {
+    if (NT == 64 && NMAX > 64 && n2 <= 256) {
       // a wave holds the whole level: sort in registers (element t in key[t >> 6] of lane t & 63)
       uint32_t key[4];
 #pragma unroll
@@ -231,9 +234,38 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
           key[sl] = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
         }
       }
-      wave_sort4(key, n2, tid);
+      wave_sort<4>(key, n2, tid);
 #pragma unroll
       for (uint32_t sl = 0; sl < 4; ++sl) {
+        const uint32_t j = sl * 64 + tid;
+        if (j < mk) {
+          const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
+          nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
+        }
+      }
+      bar();
+      uint16_t* sw = cur;
+      cur = nxt;
+      nxt = sw;
+      nk = mk;
+      if (mk == n) break;
+      continue;
+    }
+    if (NT == 64 && NMAX > 256 && n2 <= 512) {
+      // a wave holds the whole level: sort in registers (element t in key[t >> 6] of lane t & 63)
+      uint32_t key[8];
+#pragma unroll
+      for (uint32_t sl = 0; sl < 8; ++sl) {
+        const uint32_t t = sl * 64 + tid;
+        key[sl] = 0xffffffffu;
+        if (t < mk) {
+          const uint32_t e = t < nk ? cur[t] : t;
+          key[sl] = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
+        }
+      }
+      wave_sort<8>(key, n2, tid);
+#pragma unroll
+      for (uint32_t sl = 0; sl < 8; ++sl) {
         const uint32_t j = sl * 64 + tid;
         if (j < mk) {
           const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
@@ -419,7 +451,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
-  if (needs_large && needs_large[fslot] != 2u) return;  // built by the wave-per-region kernels (uniform)
+  if (needs_large && needs_large[fslot] != 3u) return;  // built by the wave-per-region kernels (uniform)
   uint32_t* pool = p.pool + (size_t)fslot * kpm_stride_u32(p.kmax);
   uint32_t* hdr = pool;
   uint32_t* pts = pool + kpm_off_pts(p.kmax);
@@ -577,7 +609,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   }
   __syncthreads();
   if (s_big) {  // uniform for the block
-    if (threadIdx.x == 0) needs_large[fslot] = k > 2048 ? 2u : 1u;  // tier: medium (1) or general (2)
+    if (threadIdx.x == 0) needs_large[fslot] = k > 4096 ? 3u : 1u;  // tier: wave-per-region instances (1, 2) or general (3)
     return;
   }
   if (threadIdx.x == 0) needs_large[fslot] = 0u;
@@ -685,7 +717,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     h[H_W1] = w1;
   }
   // iteration order of this region's code map, wave-parallel
-  umap_order_par<64>(hg[r], G, okeys[r], seq_a[r], seq_b[r], bmin[r], WaveBarrier{},
+  umap_order_par<64, 64>(hg[r], G, okeys[r], seq_a[r], seq_b[r], bmin[r], WaveBarrier{},
                      pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
@@ -694,7 +726,6 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
 // the region work) for the frames that kernel passed on (tier 1): a region's entries are
 // walked 64 at a time, the sort runs in the wave's LDS slice.  Frames with a bigger region
 // go on to the general instance (tier 2).
-constexpr uint32_t KM_RC = 256;
 
 __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint32_t* total) {
   uint32_t incl = v;
@@ -707,15 +738,18 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint3
   return incl - v;
 }
 
+// RC = entries per region the instance holds (256: 70 KB of LDS, two workgroups per CU;
+// 512: 139 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
+template <uint32_t RC, uint32_t TIN>
 __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier) {
-  __shared__ uint16_t ent[8][KM_RC], slot_of[8][KM_RC], gid_of[8][KM_RC], seq_a[8][KM_RC], seq_b[8][KM_RC];
-  __shared__ uint32_t htl[8][2 * KM_RC], keys[8][KM_RC], bmin[8][257];
-  __shared__ uint64_t hg[8][KM_RC];
+  __shared__ uint16_t ent[8][RC], slot_of[8][RC], gid_of[8][RC], seq_a[8][RC], seq_b[8][RC];
+  __shared__ uint32_t htl[8][2 * RC], keys[8][RC], bmin[8][RC == 256 ? 257 : 541];
+  __shared__ uint64_t hg[8][RC];
   __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big;
 
   const uint32_t fslot = blockIdx.x;
-  if (tier[fslot] != 1u) return;  // uniform: built already, or not yet examined
+  if (tier[fslot] != TIN) return;  // uniform: built already, or not yet examined
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
@@ -735,14 +769,14 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
       bool in = i < k && ((desc[i].region_mask >> r) & 1u);
       uint64_t bal = __builtin_amdgcn_ballot_w64(in);
       uint32_t pos = e + mbcnt(bal);
-      if (in && pos < KM_RC) ent[r][pos] = (uint16_t)i;
+      if (in && pos < RC) ent[r][pos] = (uint16_t)i;
       e += (uint32_t)__builtin_popcountll(bal);
     }
-    if (e > KM_RC && lane == 0) atomicOr(&s_big, 1u);
+    if (e > RC && lane == 0) atomicOr(&s_big, 1u);
   }
   __syncthreads();
   if (s_big) {
-    if (threadIdx.x == 0) tier[fslot] = 2u;
+    if (threadIdx.x == 0) tier[fslot] = TIN + 1u;
     return;
   }
   if (threadIdx.x == 0) tier[fslot] = 0u;
@@ -783,15 +817,15 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
     uint32_t n2 = 1;
     while (n2 < e) n2 <<= 1;
     {
-      uint32_t kreg[4];
+      uint32_t kreg[RC / 64];
 #pragma unroll
-      for (uint32_t sl = 0; sl < 4; ++sl) {
+      for (uint32_t sl = 0; sl < RC / 64; ++sl) {
         const uint32_t i = sl * 64 + lane;
         kreg[sl] = i < e ? (htl[r][slot_of[r][i]] << 16 | i) : 0xffffffffu;
       }
-      wave_sort4(kreg, n2, lane);
+      wave_sort<RC / 64>(kreg, n2, lane);
 #pragma unroll
-      for (uint32_t sl = 0; sl < 4; ++sl) keys[r][sl * 64 + lane] = kreg[sl];
+      for (uint32_t sl = 0; sl < RC / 64; ++sl) keys[r][sl * 64 + lane] = kreg[sl];
     }
     wbar();
     // 4. number the groups (first-occurrence order)
@@ -862,7 +896,7 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
   }
   wbar();
   // keys[r] is free again: iteration order of this region's code map
-  umap_order_par<64>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
+  umap_order_par<64, RC>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
 // ---- matching --------------------------------------------------------------------------------------
@@ -940,7 +974,7 @@ __device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const 
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // pos_of[k] = insertion index of the k-th iterated offset
-  umap_order_par<64>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
+  umap_order_par<64, HSLOTS>(hh, nd, okeys, seq_a, seq_b, bmin, WaveBarrier{}, pos_of, lane);
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // pos_of[k] = insertion index at iteration position k; pick the best three by
@@ -969,11 +1003,12 @@ __device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const 
 
 // One wave per (pair, region).  Pair index q: current frame = q (q = 0 pairs the halo with
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
-// Three instances.  TIER 0 (256 offset slots, 64 shared codes, 128 distinct offsets; 7 KB of
-// LDS, ~20 waves per CU) runs first on every (pair, region) and appends the item to its
-// output work list when a limit is hit; TIER 1 (1024 / 256 / 512, 30 KB) redoes exactly
-// those and passes what it cannot hold to TIER 2 (4096 / 2048 / 2048, 136 KB: one wave
-// per CU), which flags the status word instead.
+// Three instances behind kpm_match_pair, each walking the work list the one before it
+// appended to (fixed grids, no host round trip).  Offset slots / shared codes / distinct
+// offsets: TIER 0 = 256 / 256 / 128 (9 KB of LDS; the dense stream: ~110 shared codes but
+// only a handful of distinct offsets per region), TIER 1 = 1024 / 1024 / 512 (39 KB),
+// TIER 2 = 4096 / 2048 / 2048 (136 KB: one wave per CU), which flags the status word
+// instead of passing on.
 template <int TIER, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
