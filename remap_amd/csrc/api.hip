@@ -366,9 +366,18 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   tp.bands = ctx->bands;
   uint32_t n2 = 1;
   while (n2 < ctx->kmax) n2 <<= 1;
+  // LDS: the sort keys, or (if it fits 64 KB) the one-bit-per-pixel rank bitmap
+  size_t lds = n2 * sizeof(uint64_t);
+  const size_t words = ((size_t)ctx->W * ctx->H + 31) / 32;
+  tp.H = ctx->H;
+  tp.rank_words = 0;
+  if (words * 4 <= 65536) {
+    tp.rank_words = (uint32_t)words;
+    lds = std::max(lds, words * 4);
+  }
   {
     Timer t(ctx, &ctx->ms_table);
-    hipLaunchKernelGGL(kpe_table, dim3(n), dim3(256), n2 * sizeof(uint64_t), ctx->stream, tp);
+    hipLaunchKernelGGL(kpe_table, dim3(n), dim3(256), lds, ctx->stream, tp);
   }
   RMX_HIP(hipGetLastError());
   return RMX_OK;

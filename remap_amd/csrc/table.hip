@@ -18,6 +18,8 @@ struct TableParams {
   uint32_t* status;
   uint32_t n, kmax;
   Bands bands;
+  uint32_t H;          // frame height (scan order = x * H + y)
+  uint32_t rank_words;  // ceil(W * H / 32) if the rank bitmap fits the launch's LDS, else 0
 };
 
 // In-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending; blockDim.x threads.
@@ -41,14 +43,73 @@ __device__ inline void bitonic_sort_u64(uint64_t* a, uint32_t n2) {
   __syncthreads();
 }
 
+__device__ __forceinline__ void write_row(const TableParams& p, rmx_desc* out, uint32_t i, const RawDesc& r) {
+  uint32_t x = r.xy & 0xffffu, y = r.xy >> 16;
+  uint32_t m = region_mask(p.bands, x, y);
+  uint16_t* o = reinterpret_cast<uint16_t*>(out + i);
+  o[0] = (uint16_t)r.code[0];
+  o[1] = (uint16_t)(r.code[0] >> 16);
+  o[2] = (uint16_t)r.code[1];
+  o[3] = (uint16_t)(r.code[1] >> 16);
+  o[4] = (uint16_t)r.code[2];
+  o[5] = (uint16_t)(r.code[2] >> 16);
+  o[6] = (uint16_t)((r.code[3] & 0xffu) | m << 8);
+  o[7] = (uint16_t)x;
+  o[8] = (uint16_t)y;
+}
+
+// Two ways to the same table.  Few keypoints: bitonic sort of (x, y | index) keys.  Many:
+// positions are unique, so a keypoint's row is its rank in scan order — one bit per pixel in
+// an LDS bitmap indexed x * H + y, popcount prefix per thread chunk, then every record
+// computes its own row.  O(pixels / 32 + k) instead of O(k log^2 k).
 __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
-  extern __shared__ uint64_t keys[];  // next_pow2(kmax) entries
+  extern __shared__ uint64_t keys[];  // next_pow2(kmax) sort keys, or the rank bitmap
+  __shared__ uint32_t chunk_pre[256];
+  __shared__ uint32_t wave_tot[4];
   const uint32_t f = blockIdx.x;
   uint32_t k = p.kcount[f];
   if (k > p.kmax) k = p.kmax;  // overflow already flagged by kpe_main
+  const RawDesc* raw = p.raw + (size_t)f * p.kmax;
+  rmx_desc* out = p.desc + (size_t)f * p.kmax;
+  if (threadIdx.x == 0) p.kout[f] = k;
+  if (k > 128 && p.rank_words) {
+    uint32_t* bm = reinterpret_cast<uint32_t*>(keys);
+    const uint32_t nb = p.rank_words, cw = (nb + 255) / 256;
+    for (uint32_t w = threadIdx.x; w < nb; w += 256) bm[w] = 0;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+      const uint32_t xy = raw[i].xy, b = (xy & 0xffffu) * p.H + (xy >> 16);
+      atomicOr(&bm[b >> 5], 1u << (b & 31u));
+    }
+    __syncthreads();
+    const uint32_t w0 = min(nb, threadIdx.x * cw), w1 = min(nb, w0 + cw);
+    uint32_t cnt = 0;
+    for (uint32_t w = w0; w < w1; ++w) cnt += __popc(bm[w]);
+    // exclusive scan of the 256 chunk counts
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    uint32_t incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+      if (lane >= (uint32_t)o) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t w = 0; w < wave; ++w) base += wave_tot[w];
+    chunk_pre[threadIdx.x] = base + incl - cnt;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+      const RawDesc& r = raw[i];
+      const uint32_t b = (r.xy & 0xffffu) * p.H + (r.xy >> 16), w = b >> 5, c = w / cw;
+      uint32_t rank = chunk_pre[c] + __popc(bm[w] & ((1u << (b & 31u)) - 1u));
+      for (uint32_t v = c * cw; v < w; ++v) rank += __popc(bm[v]);
+      write_row(p, out, rank, r);
+    }
+    return;
+  }
   uint32_t n2 = 1;
   while (n2 < k) n2 <<= 1;
-  const RawDesc* raw = p.raw + (size_t)f * p.kmax;
   for (uint32_t i = threadIdx.x; i < n2; i += blockDim.x) {
     uint64_t key = ~0ull;
     if (i < k) {
@@ -58,23 +119,7 @@ __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
     keys[i] = key;
   }
   bitonic_sort_u64(keys, n2);
-  rmx_desc* out = p.desc + (size_t)f * p.kmax;
-  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
-    const RawDesc& r = raw[(uint32_t)keys[i]];
-    uint32_t x = r.xy & 0xffffu, y = r.xy >> 16;
-    uint32_t m = region_mask(p.bands, x, y);
-    uint16_t* o = reinterpret_cast<uint16_t*>(out + i);
-    o[0] = (uint16_t)r.code[0];
-    o[1] = (uint16_t)(r.code[0] >> 16);
-    o[2] = (uint16_t)r.code[1];
-    o[3] = (uint16_t)(r.code[1] >> 16);
-    o[4] = (uint16_t)r.code[2];
-    o[5] = (uint16_t)(r.code[2] >> 16);
-    o[6] = (uint16_t)((r.code[3] & 0xffu) | m << 8);
-    o[7] = (uint16_t)x;
-    o[8] = (uint16_t)y;
-  }
-  if (threadIdx.x == 0) p.kout[f] = k;
+  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) write_row(p, out, i, raw[(uint32_t)keys[i]]);
 }
 
 }  // namespace rmx
