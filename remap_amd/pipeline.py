@@ -21,7 +21,7 @@ import numpy as np
 
 from . import lib as L
 
-__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets"]
+__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets", "sum_subcanvases"]
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -82,6 +82,28 @@ def gather_offsets(dxdy, matched, counts, dist=None, group=None):
     parts = [allp[r, : counts[r]] for r in range(world)]
     cat = torch.cat(parts)
     return cat[:, :2].contiguous(), cat[:, 2].to(torch.uint8).contiguous()
+
+
+def sum_subcanvases(sub, zero, gbox, dist, group=None, device=None):
+    """Bin-wise sum modulo 2^16 of every rank's sub-canvas of ONE fragment (fgm.hpp:99-113).
+
+    sub: (ch, cw, 16) int16 tensor or None (no frames of the fragment on this rank); zero:
+    canvas coordinates of its top-left; gbox = (gw, gh, gzx, gzy): the fragment's whole box.
+    RCCL has no 16-bit integer type, so the sub-canvases are widened to int32, summed with
+    ONE all-reduce and narrowed again — exact: the int32 sum of at most `world` uint16 values
+    cannot overflow and its low 16 bits are the wrapped sum.  Returns (gh, gw, 16) int16."""
+    import torch as t
+
+    gw, gh, gzx, gzy = gbox
+    gloo = dist.get_backend(group) == "gloo"
+    acc = t.zeros((gh, gw, 16), dtype=t.int32, device="cpu" if gloo else device)
+    if sub is not None:
+        ch, cw = sub.shape[0], sub.shape[1]
+        y0, x0 = zero[1] - gzy, zero[0] - gzx
+        acc[y0:y0 + ch, x0:x0 + cw] += (sub.to(t.int32) & 0xffff).to(acc.device)
+    dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
+    whole = (acc & 0xffff).to(t.int16)  # int32 -> int16 keeps the low 16 bits
+    return whole if device is None else whole.to(device)
 
 
 class Aligner:
@@ -183,6 +205,34 @@ class Aligner:
             self.ctx.fgm_blit(frames, pos_l, c, (zx, zy), frag_id=frag_l, fragment=int(fid))
             canvases[int(fid)] = (c, (zx, zy), (gw, gh, (gzx, gzy)))
         return canvases
+
+    def fragments(self, frames, out):
+        """collector.complete() for a sharded stream: the whole canvas of every fragment on
+        every rank, as splice.Fragment objects (normalised: zero = (0, 0), fgm.hpp:137-143).
+
+        Each rank has blitted its own frames into step-aligned sub-boxes (`blit`); the
+        reference canvas is their bin-wise sum modulo 2^16 (`sum_subcanvases`)."""
+        from .splice import Fragment
+
+        t = self.torch
+        canv = out.get("canvases")
+        if canv is None:
+            canv = self.blit(frames, out["pos"], out["frag"], out["lo"], out["hi"])
+        pos_h = out["pos"].cpu().numpy()
+        frag_h = out["frag"].cpu().numpy()
+        result = []
+        for fid in range(int(out["nfrag"])):
+            sel = np.nonzero(frag_h == fid)[0]
+            gw, gh, gzx, gzy = self.ctx.fgm_extent(pos_h[sel])
+            mine = canv.get(fid)
+            if self.world == 1:
+                whole = mine[0]
+            else:
+                whole = sum_subcanvases(None if mine is None else mine[0], None if mine is None else mine[1],
+                                        (gw, gh, gzx, gzy), self.dist, self.group, self.ctx.device)
+            frames_list = [(int(i), (int(pos_h[i, 0]) - gzx, int(pos_h[i, 1]) - gzy)) for i in sel]
+            result.append(Fragment(whole, (0, 0), (self.W, self.H), frames_list))
+        return result
 
     def close(self):
         self.ctx.close()

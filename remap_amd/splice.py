@@ -55,6 +55,41 @@ class Fragment:
         self.frames += [(n, (x - ox + pos[0], y - oy + pos[1])) for n, (x, y) in other.frames]
 
 
+def shard_pairs(npairs, rank, world):
+    """Block-cyclic share of a pair list: indices rank, rank + world, ..."""
+    return list(range(rank, npairs, world))
+
+
+def score_pairs_sharded(score, npairs, dist=None, group=None):
+    """Cellular kpm::match votes for `npairs` fragment pairs, the pair list cut block-cyclically
+    over the ranks of `group`: every rank scores its share with `score(indices) -> VOTE_DTYPE
+    array` (one rmx_kpm_cell_pairs call) and ONE all-gather of the fixed-size vote records
+    (16 B per pair, shares padded to equal length) gives every rank the whole vote vector, in
+    pair order.  Without torch.distributed: score(all)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return score(list(range(npairs)))
+    import torch
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    mine = shard_pairs(npairs, rank, world)
+    share = (npairs + world - 1) // world
+    buf = np.zeros(share, L.VOTE_DTYPE)
+    if mine:
+        buf[: len(mine)] = score(mine)
+    flat = torch.from_numpy(buf.view(np.int32).reshape(share, 4).copy())
+    backend = dist.get_backend(group)
+    if backend != "gloo":
+        flat = flat.cuda()
+    out = torch.empty((world * share, 4), dtype=torch.int32, device=flat.device)
+    dist.all_gather_into_tensor(out, flat, group=group)
+    allv = out.cpu().numpy().reshape(world, share, 4)
+    votes = np.zeros(npairs, L.VOTE_DTYPE)
+    for r in range(world):
+        idx = shard_pairs(npairs, r, world)
+        votes[idx] = np.ascontiguousarray(allv[r, : len(idx)]).view(L.VOTE_DTYPE).reshape(-1)
+    return votes
+
+
 class _Snippet:
     def __init__(self, fragment, mask, table, k):
         self.fragment, self.mask, self.table, self.k = fragment, mask, table, k
@@ -73,9 +108,14 @@ def _extract_single(ctx_cache, frag, device):  # fgs.hpp:80-89
     return _Snippet(frag, mask, desc[0], int(kc[0].item()))
 
 
-def splice(fragments, device=0):
+def splice(fragments, device=0, dist=None, group=None):
     """fgs::splice over a list of normalised Fragments (collector.complete()).  Returns the
-    spliced fragments in the reference's list order."""
+    spliced fragments in the reference's list order.
+
+    With torch.distributed (`dist`), every rank holds the same fragments and runs the same
+    greedy loop; only the pair scoring — the O(F^2) part — is cut over the ranks
+    (score_pairs_sharded), so all ranks see identical votes and stay in step without any
+    other exchange."""
     ctxs = {}
 
     def ctx_cache(key):
@@ -87,20 +127,32 @@ def splice(fragments, device=0):
     mctx = ctx_cache("any")
     snippets = [_extract_single(ctx_cache, f, device) for f in fragments]  # extract_all, fgs.hpp:91-103
 
+    def score(members, pairs):
+        """votes of `pairs` (indices into `members`), scored on this rank's share only"""
+        def run(idx):
+            return mctx.kpm_cell_pairs([s.table for s in members], [s.k for s in members], [s.mask for s in members],
+                                       [s.fragment.dims for s in members], [pairs[i] for i in idx], CELL)
+        return score_pairs_sharded(run, len(pairs), dist, group)
+
+    def bind(head, other, v):  # snippet::bind, fgs.hpp:56-65
+        if v["valid"]:
+            off, cnt = (int(v["dx"]), int(v["dy"])), int(v["count"])
+            head.edges.append([True, off, cnt, other])
+            other.edges.append([False, (-off[0], -off[1]), cnt, head])
+
     def match_partial(head, rest):  # fgs.hpp:119-133
         if not rest:
             return
-        group = [head] + rest
-        votes = mctx.kpm_cell_pairs([s.table for s in group], [s.k for s in group], [s.mask for s in group],
-                                    [s.fragment.dims for s in group], [(0, i) for i in range(1, len(group))], CELL)
-        for v, other in zip(votes, rest):
-            if v["valid"]:
-                off, cnt = (int(v["dx"]), int(v["dy"])), int(v["count"])
-                head.edges.append([True, off, cnt, other])       # snippet::bind, fgs.hpp:56-65
-                other.edges.append([False, (-off[0], -off[1]), cnt, head])
+        members = [head] + rest
+        for v, other in zip(score(members, [(0, i) for i in range(1, len(members))]), rest):
+            bind(head, other, v)
 
-    for i in range(len(snippets) - 1):  # match_all, fgs.hpp:135-140
-        match_partial(snippets[i], snippets[i + 1:])
+    # match_all (fgs.hpp:135-140): match_partial(i, rest) for every i — one pair list, i-major,
+    # so edges are bound in the reference's order
+    all_pairs = [(i, j) for i in range(len(snippets)) for j in range(i + 1, len(snippets))]
+    if all_pairs:
+        for (i, j), v in zip(all_pairs, score(snippets, all_pairs)):
+            bind(snippets[i], snippets[j], v)
 
     while True:
         best = None  # select_match: first maximum over primary edges in list order (fgs.hpp:142-163)

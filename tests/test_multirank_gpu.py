@@ -1,0 +1,74 @@
+"""Two ranks on ONE GPU (gloo for the exchanges, both processes on cuda:0): the frame-sharded
+collect (boundary-table and offset all-gathers), the cross-rank canvas sum and the pair-sharded
+fgs::splice must reproduce the reference's golden collect -> splice result on every rank."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from remap_amd.pipeline import Aligner, shard_range
+    from remap_amd.splice import splice
+    from remap_amd.synth import rooms_v1
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = np.load(os.path.join(G, "fgs_splice.npz"))
+    n, w, h, rooms, dens, seed = g["gen"].tolist()
+    frames, _, _ = rooms_v1(n, width=w, height=h, n_rooms=rooms, dens=dens, seed=seed)
+    lo, hi = shard_range(n, rank, world)
+    local = torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda()
+    al = Aligner(w, h, kmax=2048, dist=dist)
+    out = al.align(local, n_total=n, blit=True)
+    frags = al.fragments(local, out)
+    ncollected = len(frags)
+    res = splice(frags, dist=dist)
+    from test_oracle_golden import poly_sum
+
+    summary = [(list(f.dims), poly_sum(f.canvas.cpu().numpy().view(np.uint16)), sorted(f.frames)) for f in res]
+    q.put((rank, ncollected, summary))
+    al.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_collect_sum_splice_equal_reference(gpu):
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g = np.load(os.path.join(G, "fgs_splice.npz"))
+    for rank, ncollected, summary in res:
+        assert ncollected == int(g["ncollected"]), rank
+        assert len(summary) == int(g["nfrag"]), rank
+        for k, (dims, csum, fr) in enumerate(summary):
+            assert dims == g["dims"][k].tolist(), (rank, k)
+            assert csum == int(g["canvas_sum"][k]), (rank, k)
+            for no, p in fr:
+                assert int(g["frag"][no]) == k and list(p) == g["pos"][no].tolist(), (rank, k, no)
