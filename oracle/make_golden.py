@@ -11,6 +11,7 @@ Fixtures hold inputs (or the seed of the committed generator remap_amd/synth.py 
 checksum of the generated input) and expected outputs only — never reference source.
 
     python oracle/make_golden.py          # rewrites tests/golden/
+    python oracle/make_golden.py ful      # only the fragment-file fixture (ful_case.npz)
 """
 from __future__ import annotations
 
@@ -44,7 +45,48 @@ def structured_image(rng, H, W, block=6):
     return img
 
 
+def golden_ful():
+    """Fragment files written by the reference's ful::write (ful.hpp:10-46, tier 1): two small
+    fragments, one grown to the left/top with blobs on its frames, one fresh."""
+    import tempfile
+
+    assert O.ref_strict() is not None, "run oracle/build_ref.sh first"
+    rng = np.random.default_rng(77)
+    W, H = 16, 8
+    a = O.RefFragment(W, H)
+    pos = [(0, 0), (3, 1), (-5, -2), (17, 4)]
+    for i, p in enumerate(pos):
+        img = rng.integers(0, 16, size=(H, W), dtype=np.uint8)
+        a.blit_packed(p, img, 100 + i, rng.integers(0, 256, size=int(rng.integers(0, 9)), dtype=np.uint8).tobytes(),
+                      rng.integers(0, 256, size=int(rng.integers(1, 6)), dtype=np.uint8).tobytes())
+    b = O.RefFragment(W, H)
+    b.blit((0, 0), rng.integers(0, 16, size=(H, W), dtype=np.uint8), 7)
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        O.ref_ful_write(d, [a, b])
+        names = sorted(os.listdir(d), key=int)
+        assert names == ["0", "1"]
+        for k, f in enumerate((a, b)):
+            out[f"file{k}"] = np.frombuffer(open(os.path.join(d, str(k)), "rb").read(), np.uint8)
+            out[f"dots{k}"] = f.dots()
+            out[f"info{k}"] = np.array(f.info(), np.int64)  # w, h, zero_x, zero_y, frames
+            nums, fpos = f.frames()
+            out[f"numbers{k}"] = nums
+            out[f"pos{k}"] = fpos
+            bl = f.blobs()
+            out[f"blob_sizes{k}"] = np.array([[len(x), len(y)] for x, y in bl], np.int64)
+            out[f"blob_bytes{k}"] = np.frombuffer(b"".join(x + y for x, y in bl) or b"\0", np.uint8)
+        # and the reference reads its own files back to the same fragments (step (1, 1))
+        back = O.ref_ful_read(d)
+        assert len(back) == 2 and np.array_equal(back[0].dots(), out["dots0"]) and back[0].info() == a.info()
+    out["nfiles"] = np.array(2)
+    np.savez_compressed(os.path.join(OUT, "ful_case.npz"), **out)
+    print("ful fixture:", {k: v.shape for k, v in out.items() if k.startswith("file")})
+
+
 def main():
+    if sys.argv[1:] == ["ful"]:
+        return golden_ful()
     assert O.ref_strict() is not None and O.ref_full() is not None, "run oracle/build_ref.sh first"
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261003)
@@ -217,6 +259,7 @@ def main():
                         gen=np.array([90, 128, 96, 2, 40, 3]), nfrag=np.array(sp["nfrag"]),
                         ncollected=np.array(sp["ncollected"]), frag=sp["frag"], pos=sp["pos"], dims=sp["dims"],
                         canvas_sum=sp["canvas_sum"])
+    golden_ful()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, f"({tot / 1024:.0f} KiB)")
     print("fgs: collected", sp["ncollected"], "-> spliced", sp["nfrag"], "dims", sp["dims"].tolist())

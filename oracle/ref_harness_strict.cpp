@@ -4,7 +4,8 @@
 // linked by the product.  Contains no reference code: it only calls it.
 //
 // Covers every hot-path header that g++ 11 accepts as-is (flags only: -fpermissive -w):
-//   cpl.hpp (LUTs), kpr.hpp (region/grid), kpm.hpp (both match variants), fgm.hpp (canvas).
+//   cpl.hpp (LUTs), kpr.hpp (region/grid), kpm.hpp (both match variants), fgm.hpp (canvas),
+//   ful.hpp (fragment files).
 // kpe.hpp / frc.hpp / fgs.hpp are MSVC-only as written; see ref_harness_full.cpp.
 
 // The reference headers rely on MSVC's transitive includes and on include order.
@@ -18,6 +19,7 @@
 
 #include "fgm.hpp"  // pulls icd.hpp -> sid.hpp -> cpl.hpp, mrl.hpp (kpm.hpp needs sid::)
 #include "kpm.hpp"
+#include "ful.hpp"  // fragment file format; includes fgm.hpp again (pragma once)
 
 #include "../include/remap_amd.h"
 
@@ -154,6 +156,54 @@ void ref_frag_frames(void* f, uint64_t* numbers, int32_t* pos) {
     ++i;
   }
 }
+// blit with the frame's compressed blobs attached (what frc::collector stores, frc.hpp:118)
+void ref_frag_blit_packed(void* f, int32_t px, int32_t py, const uint8_t* img, uint32_t W, uint32_t H, uint64_t no,
+                          const uint8_t* bi, uint64_t ni, const uint8_t* bm, uint64_t nm) {
+  sid::nat::dimg_t image{mrl::dimensions_t{W, H}};
+  for (std::size_t i = 0; i < image.size(); ++i) image.data()[i] = cpl::nat_cc{img[i]};
+  fgm::packed_data pk{icd::compressed_t(bi, bi + ni), icd::compressed_t(bm, bm + nm)};
+  static_cast<fgm::fragment*>(f)->blit(fgm::point_t{px, py}, image, std::move(pk), no);
+}
+void ref_frag_blob_sizes(void* f, uint64_t* ni, uint64_t* nm) {
+  std::size_t i = 0;
+  for (auto& fm : static_cast<fgm::fragment*>(f)->frames()) {
+    ni[i] = fm.data_.image_.size();
+    nm[i] = fm.data_.median_.size();
+    ++i;
+  }
+}
+void ref_frag_blobs(void* f, uint8_t* bi, uint8_t* bm) {
+  for (auto& fm : static_cast<fgm::fragment*>(f)->frames()) {
+    std::memcpy(bi, fm.data_.image_.data(), fm.data_.image_.size());
+    std::memcpy(bm, fm.data_.median_.data(), fm.data_.median_.size());
+    bi += fm.data_.image_.size();
+    bm += fm.data_.median_.size();
+  }
+}
+
+// ---- ful::write / ful::read (ful.hpp:10-102) ------------------------------------------------
+namespace {
+struct frag_ptr_iter {  // iterator over fragment handles with the `first->` shape ful::write uses
+  void** p;
+  fgm::fragment* operator->() const { return static_cast<fgm::fragment*>(*p); }
+  frag_ptr_iter& operator++() {
+    ++p;
+    return *this;
+  }
+  bool operator!=(frag_ptr_iter const& o) const { return p != o.p; }
+};
+}  // namespace
+void ref_ful_write(const char* dir, void** frags, uint32_t n) {
+  ful::write(std::filesystem::path{dir}, frag_ptr_iter{frags}, frag_ptr_iter{frags + n});
+}
+void* ref_ful_read(const char* dir, uint32_t* n) {
+  auto* v = new std::vector<fgm::fragment>(ful::read(std::filesystem::path{dir}));
+  *n = uint32_t(v->size());
+  return v;
+}
+void* ref_ful_get(void* vec, uint32_t i) { return &(*static_cast<std::vector<fgm::fragment>*>(vec))[i]; }
+void ref_ful_free(void* vec) { delete static_cast<std::vector<fgm::fragment>*>(vec); }
+
 void ref_frag_blend(void* f, uint8_t* image, uint8_t* mask) {
   auto b = static_cast<fgm::fragment*>(f)->blend();
   for (std::size_t i = 0; i < b.image_.size(); ++i) {

@@ -9,6 +9,7 @@
 #include <string>
 
 #include "frc.hpp"
+#include "ful.hpp"
 #include "mpb.hpp"
 
 // same shape as main.cpp's file_feed (main.cpp:16-52), reading from one memory blob
@@ -89,6 +90,17 @@ static int run_splice(mrl::dimensions_t dim, std::vector<std::uint8_t> const& bl
   return 0;
 }
 
+// ful::read + ful::write (ful.hpp:10-102): every fragment file of `in` through HBM and back
+static int run_ful(std::string const& in, std::string const& out) {
+  auto fragments = ful::read(in);
+  std::printf("read %zu\n", fragments.size());
+  for (auto& f : fragments)
+    std::printf("fragment dims %zu %zu zero %d %d frames %zu sum %llu\n", f.dimensions().width_, f.dimensions().height_,
+                f.zero().x_, f.zero().y_, f.frames().size(), canvas_sum(f));
+  ful::write(out, fragments.begin(), fragments.end());
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -99,6 +111,7 @@ struct seq_cfg {
 
 int main(int argc, char** argv) {
   if (argc < 4) return 2;
+  if (argc > 5 && std::string(argv[4]) == "ful") return run_ful(argv[1], argv[5]);
   const std::size_t W = std::stoul(argv[2]), H = std::stoul(argv[3]);
   std::ifstream in(argv[1], std::ios::binary);
   std::vector<std::uint8_t> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());

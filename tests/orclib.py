@@ -292,7 +292,62 @@ class RefFragment:
         self.lib.ref_frag_blend(self.h, ptr(img), ptr(mask))
         return img, mask
 
+    def blit_packed(self, pos, img, no, blob_i, blob_m):
+        img = np.ascontiguousarray(img, np.uint8)
+        H, W = img.shape
+        bi, bm = np.frombuffer(blob_i, np.uint8), np.frombuffer(blob_m, np.uint8)
+        self.lib.ref_frag_blit_packed(self.h, int(pos[0]), int(pos[1]), ptr(img), W, H, C.c_uint64(no),
+                                      ptr(bi) if len(bi) else None, C.c_uint64(len(bi)),
+                                      ptr(bm) if len(bm) else None, C.c_uint64(len(bm)))
+
+    def blobs(self):
+        *_, nf = self.info()
+        ni, nm = np.zeros(nf, np.uint64), np.zeros(nf, np.uint64)
+        self.lib.ref_frag_blob_sizes(self.h, ptr(ni), ptr(nm))
+        bi, bm = np.zeros(max(1, int(ni.sum())), np.uint8), np.zeros(max(1, int(nm.sum())), np.uint8)
+        self.lib.ref_frag_blobs(self.h, ptr(bi), ptr(bm))
+        oi = np.concatenate([[0], np.cumsum(ni)]).astype(int)
+        om = np.concatenate([[0], np.cumsum(nm)]).astype(int)
+        return [(bytes(bi[oi[k]:oi[k + 1]]), bytes(bm[om[k]:om[k + 1]])) for k in range(nf)]
+
     def __del__(self):
         if getattr(self, "h", None):
             self.lib.ref_frag_free(self.h)
             self.h = None
+
+
+def ref_ful_write(directory, fragments):
+    """ful::write of the reference (ful.hpp:10-46) over RefFragment handles."""
+    lib = ref_strict()
+    arr = (C.c_void_p * len(fragments))(*[f.h for f in fragments])
+    lib.ref_ful_write(str(directory).encode(), arr, len(fragments))
+
+
+class RefFragmentView(RefFragment):
+    """A fragment owned by a ful::read result vector (not freed on its own)."""
+
+    def __init__(self, lib, h, owner):
+        self.lib, self.h, self.owner = lib, C.c_void_p(h), owner
+
+    def __del__(self):
+        self.h = None
+
+
+class _RefFulVector:
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, C.c_void_p(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.ref_ful_free(self.h)
+            self.h = None
+
+
+def ref_ful_read(directory):
+    """ful::read of the reference (ful.hpp:48-102): list of RefFragment views."""
+    lib = ref_strict()
+    lib.ref_ful_read.restype = C.c_void_p
+    lib.ref_ful_get.restype = C.c_void_p
+    n = C.c_uint32()
+    vec = _RefFulVector(lib, lib.ref_ful_read(str(directory).encode(), C.byref(n)))
+    return [RefFragmentView(lib, lib.ref_ful_get(vec.h, i), vec) for i in range(n.value)]

@@ -177,3 +177,24 @@ def test_fgs_input_is_reproducible():
     assert hashlib.sha256(fr.tobytes()).digest() == g["input_sha256"].tobytes()
     o = O.orc_frc(fr)
     assert int(o["frag"].max()) + 1 == int(g["ncollected"])
+
+
+def test_ful_fragment_files():
+    """remap_amd.ful pack/unpack against files the reference's ful::write produced."""
+    from remap_amd import ful
+
+    g = np.load(os.path.join(G, "ful_case.npz"))
+    for k in range(int(g["nfiles"])):
+        buf = g[f"file{k}"].tobytes()
+        dots, zero, frames = ful.unpack(buf)
+        w, h, zx, zy, nf = g[f"info{k}"].tolist()
+        assert dots.shape == (h, w, 16) and np.array_equal(dots, g[f"dots{k}"])
+        assert zero == (zx, zy) and len(frames) == nf
+        sizes, blob = g[f"blob_sizes{k}"], g[f"blob_bytes{k}"].tobytes()
+        o = 0
+        for i, (no, pos, bi, bm) in enumerate(frames):
+            assert no == int(g[f"numbers{k}"][i]) and list(pos) == g[f"pos{k}"][i].tolist()
+            ni, nm = sizes[i].tolist()
+            assert bi == blob[o:o + ni] and bm == blob[o + ni:o + ni + nm]
+            o += ni + nm
+        assert ful.pack(dots, zero, frames) == buf  # byte-identical to the reference's file

@@ -70,3 +70,36 @@ def test_fragment_random_blits():
     assert np.array_equal(can, f.dots())
     a, b = O.orc_fgm_blend(can), f.blend()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+def test_reference_reads_our_fragment_files(tmp_path):
+    """ful::read of the reference parses files written by remap_amd.ful.pack (and vice versa)."""
+    from remap_amd import ful
+
+    rng = np.random.default_rng(9)
+    want = []
+    for k in range(3):
+        h, w = int(rng.integers(1, 5)) * 8, int(rng.integers(1, 4)) * 16
+        dots = rng.integers(0, 65536, size=(h, w, 16)).astype(np.uint16)
+        zero = (int(rng.integers(-40, 1)), int(rng.integers(-20, 1)))
+        frames = [(int(rng.integers(0, 1 << 40)), (int(rng.integers(-99, 99)), int(rng.integers(-99, 99))),
+                   rng.integers(0, 256, size=int(rng.integers(0, 20)), dtype=np.uint8).tobytes(),
+                   rng.integers(0, 256, size=int(rng.integers(0, 20)), dtype=np.uint8).tobytes())
+                  for _ in range(int(rng.integers(0, 6)))]
+        (tmp_path / str(k)).write_bytes(ful.pack(dots, zero, frames))
+        want.append((dots, zero, frames))
+    back = O.ref_ful_read(tmp_path)
+    assert len(back) == 3
+    for f, (dots, zero, frames) in zip(back, want):
+        w, h, zx, zy, nf = f.info()
+        assert (h, w) == dots.shape[:2] and (zx, zy) == zero and nf == len(frames)
+        assert np.array_equal(f.dots(), dots)
+        nums, pos = f.frames()
+        assert nums.tolist() == [fr[0] for fr in frames] and pos.tolist() == [list(fr[1]) for fr in frames]
+        assert f.blobs() == [(fr[2], fr[3]) for fr in frames]
+    # the reference writes them back byte-identically
+    out = tmp_path / "again"
+    out.mkdir()
+    O.ref_ful_write(out, back)
+    for k in range(3):
+        assert (out / str(k)).read_bytes() == (tmp_path / str(k)).read_bytes()
