@@ -201,6 +201,27 @@ int rmx_kpm_cell_pairs(rmx_ctx* ctx, const rmx_desc* const* tables,
                        const uint32_t* dims, uint32_t nfrag, const uint32_t* pairs,
                        uint32_t npairs, uint32_t cell_w, uint32_t cell_h, rmx_vote* votes);
 
+/* ---- nic: the frame codec on the collect loop --------------------------------------------- */
+
+/* nic::compress (nic.hpp:8-101; main.cpp:113-118 plugs it into frc::collector::collect as
+ * Comp, called for the image and the median of every frame, frc.hpp:118) for n images of
+ * `pixels` bytes each, resident on the device.  Blob i is written at out + i * stride and
+ * its size to sizes[i]; rmx_nic_bound(pixels) is a stride no image can exceed.  Bytes equal
+ * the reference's for every image inside its domain (runs <= 65535 pixels, literals <=
+ * 16383); beyond it — where the reference's uint16 counters overflow and it corrupts its
+ * heap, e.g. a blank 320x240 frame — runs and literals are split into several well-formed
+ * tokens that nic::decompress decodes to the image.  Asynchronous. */
+int rmx_nic_compress_batch(rmx_ctx* ctx, const uint8_t* images, uint32_t n, uint32_t pixels,
+                           uint8_t* out, uint32_t stride, uint32_t* sizes);
+/* Worst-case blob size of an image with `pixels` pixels (host helper, no context). */
+uint32_t rmx_nic_bound(uint32_t pixels);
+/* Gather the blobs contiguously: packed + offsets[i] <- out + i * stride, sizes[i] bytes
+ * (offsets: n uint64 on the device, normally the exclusive scan of sizes).  Asynchronous. */
+int rmx_nic_pack(rmx_ctx* ctx, const uint8_t* blobs, uint32_t stride, const uint32_t* sizes,
+                 const uint64_t* offsets, uint32_t n, uint8_t* packed);
+/* Synchronises; RMX_ERR_CAPACITY if a blob did not fit its stride since the last call. */
+int rmx_nic_status(rmx_ctx* ctx);
+
 /* ---- introspection ----------------------------------------------------------------------- */
 
 /* Library version / build string, e.g. "remap_amd 0.1 gfx950". */

@@ -12,6 +12,7 @@ checksum of the generated input) and expected outputs only — never reference s
 
     python oracle/make_golden.py          # rewrites tests/golden/
     python oracle/make_golden.py ful      # only the fragment-file fixture (ful_case.npz)
+    python oracle/make_golden.py nic      # only the codec fixture (nic_cases.npz)
 """
 from __future__ import annotations
 
@@ -84,9 +85,56 @@ def golden_ful():
     print("ful fixture:", {k: v.shape for k, v in out.items() if k.startswith("file")})
 
 
+def nic_inputs():
+    """Inputs of the nic fixture (all inside the reference's domain: runs <= 65535 pixels,
+    literals <= 16383 — outside it nic::compress corrupts its heap)."""
+    rng = np.random.default_rng(4242)
+    fr, _ = scroller_v1(4, dens=200)
+    frd, _ = scroller_v1(2, dens=40)
+    a = np.zeros((20, 100), np.uint8)
+    a[:, ::4] = 5
+    cases = [fr[0], fr[3], frd[1], rng.integers(0, 16, size=(64, 200), dtype=np.uint8),
+             rng.integers(0, 2, size=(48, 300), dtype=np.uint8), a, np.full((100, 600), 7, np.uint8),
+             np.kron(rng.integers(0, 16, size=(10, 40), dtype=np.uint8), np.ones((1, 7), np.uint8)),
+             np.kron(rng.integers(0, 16, size=(6, 5), dtype=np.uint8), np.ones((1, 300), np.uint8)),
+             np.full((1, 65535), 3, np.uint8), np.array([[1]], np.uint8), np.array([[1, 1]], np.uint8),
+             np.array([[1, 1, 1]], np.uint8), np.array([[1, 2, 2, 2]], np.uint8), np.array([[1, 2, 3, 3, 3, 4]], np.uint8)]
+    lit = rng.integers(0, 16, size=16383, dtype=np.uint8)  # the longest literal the header can express
+    lit[1:][lit[1:] == lit[:-1]] ^= 1
+    cases.append(np.concatenate([lit, [lit[-1] ^ 2] * 3]).astype(np.uint8)[None])
+    for _ in range(200):
+        n = int(rng.integers(1, 400))
+        p = rng.random() ** 2
+        x = np.zeros(n, np.uint8)
+        v = int(rng.integers(0, 16))
+        for i in range(n):
+            if rng.random() < p:
+                v = int(rng.integers(0, 16))
+            x[i] = v
+        cases.append(x[None])
+    return cases
+
+
+def golden_nic():
+    """nic::compress of the reference (nic.hpp:8-101, tier 1, unmodified) on nic_inputs()."""
+    assert O.ref_strict() is not None, "run oracle/build_ref.sh first"
+    cases = nic_inputs()
+    out = {"ncases": np.array(len(cases)), "shapes": np.array([c.shape for c in cases], np.int64),
+           "pixels": np.concatenate([c.reshape(-1) for c in cases])}
+    packs = [O.ref_nic_compress(c) for c in cases]
+    for c, pk in zip(cases, packs):
+        assert np.array_equal(O.ref_nic_decompress(pk, c.shape[1], c.shape[0]), c)
+    out["sizes"] = np.array([len(pk) for pk in packs], np.int64)
+    out["packed"] = np.frombuffer(b"".join(packs), np.uint8)
+    np.savez_compressed(os.path.join(OUT, "nic_cases.npz"), **out)
+    print("nic fixture:", len(cases), "cases,", int(out["sizes"].sum()), "compressed bytes")
+
+
 def main():
     if sys.argv[1:] == ["ful"]:
         return golden_ful()
+    if sys.argv[1:] == ["nic"]:
+        return golden_nic()
     assert O.ref_strict() is not None and O.ref_full() is not None, "run oracle/build_ref.sh first"
     os.makedirs(OUT, exist_ok=True)
     rng = np.random.default_rng(20261003)
@@ -260,6 +308,7 @@ def main():
                         ncollected=np.array(sp["ncollected"]), frag=sp["frag"], pos=sp["pos"], dims=sp["dims"],
                         canvas_sum=sp["canvas_sum"])
     golden_ful()
+    golden_nic()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, f"({tot / 1024:.0f} KiB)")
     print("fgs: collected", sp["ncollected"], "-> spliced", sp["nfrag"], "dims", sp["dims"].tolist())

@@ -19,6 +19,7 @@
 
 #include "fgm.hpp"  // pulls icd.hpp -> sid.hpp -> cpl.hpp, mrl.hpp (kpm.hpp needs sid::)
 #include "kpm.hpp"
+#include "nic.hpp"  // the codec main.cpp plugs into collect as Comp (main.cpp:113-125)
 #include "ful.hpp"  // fragment file format; includes fgm.hpp again (pragma once)
 
 #include "../include/remap_amd.h"
@@ -179,6 +180,19 @@ void ref_frag_blobs(void* f, uint8_t* bi, uint8_t* bm) {
     bi += fm.data_.image_.size();
     bm += fm.data_.median_.size();
   }
+}
+
+// ---- nic::compress / nic::decompress (nic.hpp:8-166) -----------------------------------------
+uint64_t ref_nic_compress(const uint8_t* px, uint32_t W, uint32_t H, uint8_t* out, uint64_t cap) {
+  sid::nat::dimg_t image{mrl::dimensions_t{W, H}};
+  for (std::size_t i = 0; i < image.size(); ++i) image.data()[i] = cpl::nat_cc{px[i]};
+  auto r = nic::compress(image);
+  std::memcpy(out, r.data(), std::min<std::size_t>(cap, r.size()));
+  return r.size();
+}
+void ref_nic_decompress(const uint8_t* pack, uint64_t size, uint32_t W, uint32_t H, uint8_t* out) {
+  auto img = nic::decompress(icd::compressed_t(pack, pack + size), mrl::dimensions_t{W, H});
+  for (std::size_t i = 0; i < img.size(); ++i) out[i] = img.data()[i].value;
 }
 
 // ---- ful::write / ful::read (ful.hpp:10-102) ------------------------------------------------

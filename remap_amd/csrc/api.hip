@@ -17,6 +17,7 @@
 #include "kpm.hip"
 #include "kpm_cell.hip"
 #include "fgm.hip"
+#include "nic.hip"
 
 using namespace rmx;
 
@@ -50,7 +51,7 @@ struct rmx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
   };
-  Track ms_kpe, ms_finish, ms_table, ms_kpm_build, ms_kpm_match, ms_blit;
+  Track ms_kpe, ms_finish, ms_table, ms_kpm_build, ms_kpm_match, ms_blit, ms_nic;
   std::string err;
 };
 
@@ -195,7 +196,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) free_track(*t);
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic}) free_track(*t);
   delete ctx;
   return RMX_OK;
 }
@@ -214,7 +215,7 @@ int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   ctx->timing = enabled != 0;
   // (re)start a measurement window: forget the pairs recorded so far
   RMX_HIP(hipStreamSynchronize(ctx->stream));
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit}) t->used = 0;
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic}) t->used = 0;
   return RMX_OK;
 }
 
@@ -242,6 +243,8 @@ static int kernel_stats(rmx_ctx* ctx, const char* kernel, float* ms, uint32_t* l
     t = &ctx->ms_kpm_match;
   else if (k == "fgm_blit")
     t = &ctx->ms_blit;
+  else if (k == "nic_compress")
+    t = &ctx->ms_nic;
   else
     return RMX_ERR_ARG;
   RMX_HIP(hipStreamSynchronize(ctx->stream));

@@ -32,7 +32,7 @@ SYMBOLS = [
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
-    "rmx_memset",
+    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status",
 ]
 
 
@@ -106,6 +106,20 @@ def load():
     lib.rmx_fgm_blend.argtypes = [vp, vp, u32, u32, vp, vp]
     lib.rmx_kpm_cell_pairs.argtypes = [vp, vp, vp, vp, vp, u32, vp, u32, u32, u32, vp]
     lib.rmx_luts.argtypes = [vp, vp]
+    lib.rmx_nic_compress_batch.argtypes = [vp, vp, u32, u32, vp, u32, vp]
+    lib.rmx_nic_bound.argtypes = [u32]
+    lib.rmx_nic_bound.restype = u32
+    lib.rmx_nic_pack.argtypes = [vp, vp, u32, vp, vp, u32, vp]
+    lib.rmx_nic_status.argtypes = [vp]
+    sz = C.c_size_t
+    lib.rmx_malloc.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.rmx_free.argtypes = [vp, vp]
+    lib.rmx_upload.argtypes = [vp, vp, vp, sz]
+    lib.rmx_download.argtypes = [vp, vp, vp, sz]
+    lib.rmx_download_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
+    lib.rmx_copy.argtypes = [vp, vp, vp, sz]
+    lib.rmx_memset.argtypes = [vp, vp, C.c_int, sz]
+    lib.rmx_version.argtypes = []
     lib.rmx_set_timing.argtypes = [vp, C.c_int]
     lib.rmx_last_kernel_ms.argtypes = [vp, C.c_char_p, C.POINTER(C.c_float)]
     lib.rmx_kernel_launches.argtypes = [vp, C.c_char_p, C.POINTER(u32)]
@@ -253,6 +267,33 @@ class Context:
         self._chk(self.lib.rmx_frc_scan(self.h, dxdy.data_ptr(), matched.data_ptr(), n, int(first_is_start), cp,
                                         C.byref(cf), pos.data_ptr(), frag.data_ptr()), "rmx_frc_scan")
         return pos, frag, ((cp[0], cp[1]), cf.value)
+
+    # ---- nic -------------------------------------------------------------------------------
+    def nic_compress(self, images, pack=True):
+        """nic::compress of every image of `images` ((n, ...) uint8 CUDA tensor, one image per
+        leading index).  pack=True: (packed uint8 CUDA tensor, sizes int64 host array) with
+        blob i at packed[offsets[i]:offsets[i] + sizes[i]], offsets = exclusive cumsum;
+        pack=False: (blobs (n, stride) CUDA tensor, sizes CUDA tensor)."""
+        t = self.torch
+        assert images.is_cuda and images.dtype == t.uint8 and images.is_contiguous()
+        n = images.shape[0]
+        pixels = images[0].numel()
+        stride = int(self.lib.rmx_nic_bound(pixels))
+        blobs = t.empty((n, stride), dtype=t.uint8, device=self.device)
+        sizes = t.empty(n, dtype=t.int32, device=self.device)
+        self._chk(self.lib.rmx_nic_compress_batch(self.h, images.data_ptr(), n, pixels, blobs.data_ptr(), stride,
+                                                  sizes.data_ptr()), "rmx_nic_compress_batch")
+        if not pack:
+            return blobs, sizes
+        self._chk(self.lib.rmx_nic_status(self.h), "rmx_nic_status")
+        sz = sizes.cpu().numpy().astype(np.int64)
+        offs = np.concatenate([[0], np.cumsum(sz)[:-1]]).astype(np.uint64)
+        packed = t.empty(int(sz.sum()), dtype=t.uint8, device=self.device)
+        doffs = t.from_numpy(offs.view(np.int64)).to(self.device)
+        self._chk(self.lib.rmx_nic_pack(self.h, blobs.data_ptr(), stride, sizes.data_ptr(), doffs.data_ptr(), n,
+                                        packed.data_ptr()), "rmx_nic_pack")
+        self.sync()
+        return packed, sz
 
     # ---- fgm -------------------------------------------------------------------------------
     def fgm_extent(self, pos_host):

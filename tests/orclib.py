@@ -127,6 +127,42 @@ def orc_kpm_cell(prev, pmask, cur, cdims, cell=(15, 15)):
     return m, v[0]
 
 
+def orc_nic_compress(img):
+    px = np.ascontiguousarray(img, np.uint8).reshape(-1)
+    out = np.zeros(len(px) + 64, np.uint8)
+    lib = oracle()
+    lib.orc_nic_compress.restype = C.c_uint64
+    n = lib.orc_nic_compress(ptr(px), C.c_uint64(len(px)), ptr(out), C.c_uint64(len(out)))
+    assert n <= len(out)
+    return out[:n].tobytes()
+
+
+def orc_nic_decompress(pack, npix):
+    b = np.frombuffer(pack, np.uint8)
+    out = np.zeros(npix, np.uint8)
+    lib = oracle()
+    lib.orc_nic_decompress.restype = C.c_uint64
+    n = lib.orc_nic_decompress(ptr(b), C.c_uint64(len(b)), ptr(out), C.c_uint64(npix))
+    return out, int(n)
+
+
+def ref_nic_compress(img):
+    img = np.ascontiguousarray(img, np.uint8)
+    H, W = img.shape
+    out = np.zeros(img.size + 64, np.uint8)
+    lib = ref_strict()
+    lib.ref_nic_compress.restype = C.c_uint64
+    n = lib.ref_nic_compress(ptr(img), W, H, ptr(out), C.c_uint64(len(out)))
+    return out[:n].tobytes()
+
+
+def ref_nic_decompress(pack, W, H):
+    b = np.frombuffer(pack, np.uint8)
+    out = np.zeros((H, W), np.uint8)
+    ref_strict().ref_nic_decompress(ptr(b), C.c_uint64(len(b)), W, H, ptr(out))
+    return out
+
+
 def orc_umap_order(hashes):
     h = np.ascontiguousarray(hashes, np.uint64)
     o = np.zeros(len(h), np.uint32)

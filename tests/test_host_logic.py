@@ -91,7 +91,15 @@ def test_c_abi_exports_every_declared_symbol():
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     so = L.load()  # builds with hipcc if needed; loading needs no GPU
     for name in declared:
-        assert getattr(so, name) is not None
+        fn = getattr(so, name)
+        assert fn is not None
+        # every entry point has a ctypes prototype: without one ctypes passes Python ints as
+        # 32-bit C ints and a device pointer is silently truncated
+        assert fn.argtypes is not None, name
+        params = re.search(r"^[a-z][a-z_0-9 *]*?\b" + name + r"\s*\(([^;]*?)\)\s*;", hdr, re.S | re.M).group(1)
+        n_params = 0 if params.strip() == "void" else len(params.split(","))
+        if fn.argtypes or n_params == 0:
+            assert len(fn.argtypes) == n_params, (name, len(fn.argtypes), n_params)
     assert so.rmx_version().startswith(b"remap_amd")
     a, b = L.luts()
     assert a.tolist() == O.orc_luts()[0].tolist() and b.tolist() == O.orc_luts()[1].tolist()

@@ -1,0 +1,87 @@
+"""nic::compress on the GPU (rmx_nic_compress_batch) against the reference's golden streams
+and the CPU oracle, through the C ABI."""
+import numpy as np
+import pytest
+
+import orclib as O
+from remap_amd import lib as L
+from remap_amd.synth import scroller_v1
+from test_oracle_golden import nic_cases
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_compress(ctx, imgs):
+    """imgs: list of equally sized uint8 arrays -> list of compressed byte strings"""
+    import torch
+
+    batch = torch.from_numpy(np.stack([np.ascontiguousarray(i).reshape(-1) for i in imgs])).cuda()
+    packed, sizes = ctx.nic_compress(batch)
+    pk = packed.cpu().numpy().tobytes()
+    offs = np.concatenate([[0], np.cumsum(sizes)])
+    return [pk[offs[i]:offs[i + 1]] for i in range(len(imgs))]
+
+
+def test_nic_golden_cases(gpu):
+    ctx = L.Context(16, 8, grid=(1, 1), overlap=0, kmax=64)
+    by_size = {}
+    for k, img, pk in nic_cases():
+        by_size.setdefault(img.size, []).append((k, img, pk))
+    for size, group in by_size.items():  # one batch per image size
+        got = gpu_compress(ctx, [g[1] for g in group])
+        for (k, img, pk), g in zip(group, got):
+            assert g == pk, (k, img.shape, len(g), len(pk))
+    ctx.close()
+
+
+def test_nic_frames_and_medians_match_oracle(gpu):
+    import torch
+
+    fr = np.concatenate([scroller_v1(24, dens=200)[0], scroller_v1(8, dens=40)[0]])
+    ctx = L.Context(320, 240, kmax=2048)
+    d = torch.from_numpy(fr).cuda()
+    med, _, _ = ctx.kpe(d)
+    for plane in (d, med):
+        got = gpu_compress(ctx, list(plane.cpu().numpy()))
+        for i, g in enumerate(got):
+            assert g == O.orc_nic_compress(plane[i].cpu().numpy()), i
+    ctx.close()
+
+
+def test_nic_beyond_reference_domain(gpu):
+    # a blank frame (one run of 76800 > 65535), pure noise (literal of 76800 > 16383), runs of
+    # 65536..65538 and 2 x 65535 +- 1: split tokens, equal to the oracle, and they decode
+    rng = np.random.default_rng(8)
+    P = 320 * 240
+    imgs = [np.full(P, 6, np.uint8), rng.integers(0, 16, size=P, dtype=np.uint8)]
+    for r in (65536, 65537, 65538, 76797):
+        x = rng.integers(0, 16, size=P, dtype=np.uint8)
+        x[2:2 + r] = 9
+        imgs.append(x)
+    x = np.zeros(P, np.uint8)
+    x[::2] = 1  # literal with no run at all
+    imgs.append(x)
+    ctx = L.Context(320, 240, kmax=64)
+    got = gpu_compress(ctx, imgs)
+    for i, (img, g) in enumerate(zip(imgs, got)):
+        assert g == O.orc_nic_compress(img), i
+        dec, cnt = O.orc_nic_decompress(g, P)
+        assert cnt == P and np.array_equal(dec, img), i
+    ctx.close()
+
+
+def test_nic_stride_too_small_is_reported(gpu):
+    import ctypes as C
+
+    import torch
+
+    ctx = L.Context(16, 8, kmax=64, grid=(1, 1), overlap=0)
+    img = torch.from_numpy(np.random.default_rng(1).integers(0, 16, size=(2, 4096), dtype=np.uint8)).cuda()
+    blobs = torch.zeros((2, 64), dtype=torch.uint8, device="cuda")
+    sizes = torch.zeros(2, dtype=torch.int32, device="cuda")
+    rc = ctx.lib.rmx_nic_compress_batch(ctx.h, img.data_ptr(), 2, 4096, blobs.data_ptr(), 64, sizes.data_ptr())
+    assert rc == 0
+    assert ctx.lib.rmx_nic_status(ctx.h) == -4  # RMX_ERR_CAPACITY
+    assert int(sizes[0]) > 64  # the true size is still reported
+    assert ctx.lib.rmx_nic_status(ctx.h) == 0
+    ctx.close()

@@ -198,3 +198,44 @@ def test_ful_fragment_files():
             assert bi == blob[o:o + ni] and bm == blob[o + ni:o + ni + nm]
             o += ni + nm
         assert ful.pack(dots, zero, frames) == buf  # byte-identical to the reference's file
+
+
+def nic_cases():
+    g = np.load(os.path.join(G, "nic_cases.npz"))
+    po, ko = 0, 0
+    for k in range(int(g["ncases"])):
+        h, w = g["shapes"][k].tolist()
+        img = g["pixels"][po:po + h * w].reshape(h, w)
+        pk = g["packed"][ko:ko + int(g["sizes"][k])].tobytes()
+        po += h * w
+        ko += int(g["sizes"][k])
+        yield k, img, pk
+
+
+def test_nic_compress_cases():
+    """oracle nic codec == the reference's nic::compress bytes on every golden case; decode inverts."""
+    n = 0
+    for k, img, pk in nic_cases():
+        assert O.orc_nic_compress(img) == pk, k
+        d, cnt = O.orc_nic_decompress(pk, img.size)
+        assert cnt == img.size and np.array_equal(d, img.reshape(-1)), k
+        n += 1
+    assert n > 200
+
+
+def test_nic_beyond_the_reference_domain_round_trips():
+    """runs > 65535 pixels and literals > 16383 (where the reference overflows its uint16
+    counters) are split into well-formed tokens that decode to the input."""
+    rng = np.random.default_rng(8)
+    blank = np.full(76800, 6, np.uint8)
+    noise = rng.integers(0, 16, size=76800, dtype=np.uint8)
+    for r in (65536, 65537, 65538, 131070, 131071, 131073):
+        x = np.concatenate([[1, 2], np.full(r, 9, np.uint8), [3]]).astype(np.uint8)
+        pk = O.orc_nic_compress(x)
+        d, cnt = O.orc_nic_decompress(pk, x.size)
+        assert cnt == x.size and np.array_equal(d, x), r
+    for x in (blank, noise):
+        pk = O.orc_nic_compress(x)
+        d, cnt = O.orc_nic_decompress(pk, x.size)
+        assert cnt == x.size and np.array_equal(d, x)
+    assert O.orc_nic_compress(blank).hex() == "66ffff66012c"  # 65535 + 11265
