@@ -7,12 +7,9 @@
 // grammar (oracle/remap_oracle.cpp, orc_nic_compress): maximal runs of >= 3 equal pixels
 // become REP tokens, every maximal stretch of shorter runs becomes one LITERAL token.
 //
-// One workgroup per image; thread t owns a contiguous chunk of pixels.  Tokens are
-// attributed to the thread that owns their LAST pixel, which can size them from two carried
-// facts: how long the run reaching into its chunk already is (segmented scan over chunk
-// summaries) and where the last completed long run ended (max-scan).  A sum-scan of the
-// per-chunk byte counts then gives every token its output offset — three block scans and
-// three sequential walks over 1/256 of the image per thread, no atomics, output bytes
+// One workgroup per image, which it takes in LDS-sized segments; inside a segment thread t
+// owns a contiguous chunk of pixels and the tokens whose LAST pixel lies in it (details at the
+// kernel).  Two block scans per segment, no atomics, output bytes
 // identical to the reference's for every input inside its domain (runs <= 65535 pixels,
 // literals <= 16383); beyond it, where the reference overflows its uint16 counters, runs and
 // literals are split into several well-formed tokens (same rule as the oracle).
@@ -28,7 +25,7 @@ struct NicParams {
   uint32_t n, pixels, stride;
 };
 
-__device__ __forceinline__ uint32_t nic_rep_bytes(uint32_t len) {
+__device__ __noinline__ uint32_t nic_rep_bytes_split(uint32_t len) {
   uint32_t b = 0;
   while (len > 65535u) {  // split: 65535-pixel pieces, never leaving a remainder < 3
     uint32_t piece = 65535u;
@@ -38,13 +35,19 @@ __device__ __forceinline__ uint32_t nic_rep_bytes(uint32_t len) {
   }
   return b + (len <= 6u ? 1u : len <= 255u ? 2u : 3u);
 }
-__device__ __forceinline__ uint32_t nic_lit_bytes(uint32_t n) {
+__device__ __forceinline__ uint32_t nic_rep_bytes(uint32_t len) {
+  return len <= 6u ? 1u : len <= 255u ? 2u : len <= 65535u ? 3u : nic_rep_bytes_split(len);
+}
+__device__ __noinline__ uint32_t nic_lit_bytes_split(uint32_t n) {
   uint32_t b = 0;
   while (n > 16383u) {  // split: even pieces of 16382 keep the nibble packing aligned
     b += 2 + 8191;
     n -= 16382u;
   }
   return b + (n < 64u ? 1u : 2u) + (n + 1) / 2;
+}
+__device__ __forceinline__ uint32_t nic_lit_bytes(uint32_t n) {
+  return n < 64u ? 1u + ((n + 1) >> 1) : nic_lit_bytes_split(n);
 }
 __device__ inline uint8_t* nic_emit_rep(uint8_t* o, uint32_t v, uint32_t len) {
   while (len > 0) {
@@ -67,7 +70,8 @@ __device__ inline uint8_t* nic_emit_rep(uint8_t* o, uint32_t v, uint32_t len) {
   }
   return o;
 }
-__device__ inline uint8_t* nic_emit_lit(uint8_t* o, const uint8_t* px, uint32_t n) {
+template <typename Px>
+__device__ __forceinline__ uint8_t* nic_emit_lit(uint8_t* __restrict__ o, Px&& pixel, uint32_t s, uint32_t n) {
   while (n > 0) {
     const uint32_t piece = n > 16383u ? 16382u : n;
     if (piece < 64u) {
@@ -77,163 +81,217 @@ __device__ inline uint8_t* nic_emit_lit(uint8_t* o, const uint8_t* px, uint32_t 
       *o++ = (uint8_t)piece;
     }
     for (uint32_t j = 0; j < piece; j += 2)
-      *o++ = (uint8_t)((px[j] & 15u) << 4 | (j + 1 < piece ? (px[j + 1] & 15u) : 0u));
-    px += piece;
+      *o++ = (uint8_t)(pixel(s + j) << 4 | (j + 1 < piece ? pixel(s + j + 1) : 0u));
+    s += piece;
     n -= piece;
   }
   return o;
 }
 
-// 256-thread inclusive scans through wave shuffles + four wave totals
-struct NicSeg {
-  uint32_t reset, x;  // x = run length reaching the chunk's last pixel
-};
-__device__ __forceinline__ NicSeg nic_join(const NicSeg& a, const NicSeg& b) {
-  return NicSeg{a.reset | b.reset, b.reset ? b.x : a.x + b.x};
-}
-
 constexpr uint32_t NIC_T = 256;
+constexpr uint32_t NIC_CW = 19;                    // dwords per thread and segment (odd: thread t's
+                                                   // k-th word sits in bank (19 t + k) mod 64, conflict-free)
+constexpr uint32_t NIC_SEG = NIC_T * NIC_CW * 4;   // pixels per segment (19 456; 19 KB of LDS)
+constexpr uint32_t NIC_OUT = 64 * NIC_CW * 3;      // bytes a wave's chunks can produce from tokens of their own
+                                                   // pixels (3/4 byte per pixel); staged in LDS, written coalesced
+constexpr uint32_t NIC_WORDS = NIC_T * NIC_CW + 4; // + 4 pixels before, 12 after (stencil reach)
 
+// byte-wise flags (bit 7 of each byte) -> 4 bits
+__device__ __forceinline__ uint32_t nic_nib(uint32_t x) { return ((x >> 7) | (x >> 14) | (x >> 21) | (x >> 28)) & 0xfu; }
+
+// The image is taken in segments that fit LDS (coalesced dword loads, one pixel per byte).
+// Token boundaries are a LOCAL property of the pixel sequence:
+//   eq[i] = px[i] == px[i+1]            t[i] = eq[i] & eq[i+1]  (three equal pixels from i)
+//   L[i]  = t[i] | t[i-1] | t[i-2]      (pixel i lies in a run of >= 3)
+//   T[i]  = L[i] ? !eq[i] : L[i+1]      (pixel i is the LAST pixel of a token; P - 1 always is)
+// so every thread derives the L and T bits of its 76 pixels with byte-parallel ALU ops on
+// 19 dwords (no walk, no divergence) and a token's length is the distance to the previous
+// T bit — carried across chunks by a max-scan and across segments in LDS.  Sizes -> sum-scan
+// -> offsets -> emission, both loops running over the chunk's tokens, not its pixels.
 __global__ __launch_bounds__(NIC_T) void nic_compress(NicParams p) {
-  __shared__ NicSeg s_seg[4];
+  __shared__ uint32_t s_px[NIC_WORDS];  // word w <-> pixels seg0 - 4 + 4 w ...
+  __shared__ uint8_t s_out[4][NIC_OUT];
   __shared__ int32_t s_max[4];
   __shared__ uint32_t s_sum[4];
+  __shared__ uint32_t s_off;  // carried: bytes so far
+  __shared__ int32_t s_end;   // carried: last pixel of the last token that ended
   const uint32_t f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint8_t* px = p.images + (size_t)f * p.pixels;
   const uint32_t P = p.pixels;
-  const uint32_t cp = (P + NIC_T - 1) / NIC_T;
-  const uint32_t c0 = min(P, tid * cp), c1 = min(P, c0 + cp);
-  const bool has = c1 > c0;
-  auto at = [&](uint32_t i) { return (uint32_t)px[i] & 15u; };
-
-  // ---- walk 1: chunk summary (is it one run, and the run reaching its last pixel) ----
-  uint32_t tail = 0;
-  bool uniform = true;
-  if (has) {
-    uint32_t v = at(c0);
-    tail = 1;
-    for (uint32_t i = c0 + 1; i < c1; ++i) {
-      const uint32_t w = at(i);
-      if (w == v) {
-        ++tail;
-      } else {
-        v = w;
-        tail = 1;
-        uniform = false;
-      }
-    }
+  if (tid == 0) {
+    s_off = 0;
+    s_end = -1;
   }
-  // run length at the chunk end = own length + the predecessor's, iff the chunk is one run
-  // that continues the previous pixel; otherwise the in-chunk tail (a reset)
-  const bool cont = has && c0 > 0 && at(c0 - 1) == at(c0);
-  NicSeg inc{(uint32_t)!(uniform && cont), tail};
-  if (!has) inc = NicSeg{0u, 0u};
+  bool fits = true;  // once the blob would pass the stride nothing more is written (flagged at the end)
+
+  for (uint32_t seg0 = 0; seg0 < P; seg0 += NIC_SEG) {
+    __syncthreads();  // previous segment fully consumed; carried values visible
+    // stage [seg0 - 4, seg0 + NIC_SEG + 12): global dword loads at any byte alignment, all in
+    // flight before the first LDS store; pixels outside the image become 0x10 / 0x11
+    // alternating, equal to nothing next to them (a word that straddles the image's edge is
+    // patched byte by byte)
+    {
+      auto patch = [&](int64_t g) {
+        uint32_t v = 0x11101110u;
+        for (int b = 0; b < 4; ++b)
+          if (g + b >= 0 && g + b < (int64_t)P) v = (v & ~(0xffu << (8 * b))) | ((uint32_t)px[g + b] & 15u) << (8 * b);
+        return v;
+      };
+      uint32_t r[NIC_CW + 1];
+      const int32_t g0 = (int32_t)seg0 - 4 + 4 * (int32_t)tid, Pi = (int32_t)P;  // (images < 2^31 pixels)
+      if (P >= 8) {
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    NicSeg t{(uint32_t)__shfl_up((int)inc.reset, o), (uint32_t)__shfl_up((int)inc.x, o)};
-    if (lane >= (uint32_t)o) inc = nic_join(t, inc);
-  }
-  if (lane == 63) s_seg[wave] = inc;
-  __syncthreads();
-  NicSeg pre{0u, 0u};
-  for (uint32_t w = 0; w < wave; ++w) pre = nic_join(pre, s_seg[w]);
-  NicSeg before{(uint32_t)__shfl_up((int)inc.reset, 1), (uint32_t)__shfl_up((int)inc.x, 1)};
-  if (lane == 0) before = NicSeg{0u, 0u};
-  const NicSeg left = nic_join(pre, before);  // run reaching pixel c0 - 1
-  const uint32_t rl0 = cont ? left.x : 0u;    // pixels of c0's run that lie before the chunk
-
-  // a run is visited at its LAST pixel e (e == P - 1 or px[e + 1] differs)
-  // ---- walk 2: last long-run end inside the chunk ----
-  int32_t last_long = -1;
-  if (has) {
-    uint32_t v = at(c0), len = rl0 + 1;
-    for (uint32_t i = c0; i < c1; ++i) {
-      const bool end = i + 1 == P || at(i + 1) != v;
-      if (end) {
-        if (len >= 3) last_long = (int32_t)i;
-        if (i + 1 < P) v = at(i + 1);
-        len = 1;
-      } else {
-        ++len;
-      }
-    }
-  }
-  int32_t mx = last_long;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const int32_t t = __shfl_up(mx, o);
-    if (lane >= (uint32_t)o) mx = max(mx, t);
-  }
-  if (lane == 63) s_max[wave] = mx;
-  __syncthreads();
-  int32_t carried = -1;
-  for (uint32_t w = 0; w < wave; ++w) carried = max(carried, s_max[w]);
-  {
-    const int32_t t = __shfl_up(mx, 1);
-    if (lane > 0) carried = max(carried, t);
-  }
-  // carried = last pixel of the last long run that ended before this chunk (-1: none)
-
-  // ---- walk 3 / 4: size, then emit, the tokens that END in this chunk ----
-  // A literal ends at e if e closes a short run and (e == P - 1 or a long run starts at e + 1).
-  auto long_starts = [&](uint32_t i) {  // run starting at i has >= 3 pixels
-    return i + 2 < P && at(i + 1) == at(i) && at(i + 2) == at(i);
-  };
-  uint32_t bytes = 0;
-  if (has) {
-    uint32_t v = at(c0), len = rl0 + 1;
-    int32_t ll = carried;
-    for (uint32_t i = c0; i < c1; ++i) {
-      const bool end = i + 1 == P || at(i + 1) != v;
-      if (end) {
-        if (len >= 3) {
-          bytes += nic_rep_bytes(len);
-          ll = (int32_t)i;
-        } else if (i + 1 == P || long_starts(i + 1)) {
-          bytes += nic_lit_bytes(i - (uint32_t)(ll + 1) + 1);
+        for (int it = 0; it <= (int)NIC_CW; ++it) {
+          const int32_t g = g0 + it * (int32_t)(4 * NIC_T);
+          const int32_t gc = max(0, min(g, Pi - 4));
+          r[it] = (it < (int)NIC_CW || tid < 4) ? *reinterpret_cast<const uint32_t*>(px + gc) & 0x0f0f0f0fu : 0u;
         }
-        if (i + 1 < P) v = at(i + 1);
-        len = 1;
-      } else {
-        ++len;
       }
-    }
-  }
-  uint32_t sum = bytes;
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const uint32_t t = (uint32_t)__shfl_up((int)sum, o);
-    if (lane >= (uint32_t)o) sum += t;
-  }
-  if (lane == 63) s_sum[wave] = sum;
-  __syncthreads();
-  uint32_t off = sum - bytes;
-  for (uint32_t w = 0; w < wave; ++w) off += s_sum[w];
-  if (tid == NIC_T - 1) {
-    const uint32_t total = off + bytes;
-    p.sizes[f] = total;
-    if (total > p.stride) atomicOr(&p.status[2], 1u);
-  }
-  if (has && off + bytes <= p.stride) {  // (a frame that does not fit is flagged, nothing of this chunk is written)
-    uint8_t* o = p.out + (size_t)f * p.stride + off;
-    uint32_t v = at(c0), len = rl0 + 1;
-    int32_t ll = carried;
-    for (uint32_t i = c0; i < c1; ++i) {
-      const bool end = i + 1 == P || at(i + 1) != v;
-      if (end) {
-        if (len >= 3) {
-          o = nic_emit_rep(o, v, len);
-          ll = (int32_t)i;
-        } else if (i + 1 == P || long_starts(i + 1)) {
-          const uint32_t s = (uint32_t)(ll + 1);
-          o = nic_emit_lit(o, px + s, i - s + 1);
-        }
-        if (i + 1 < P) v = at(i + 1);
-        len = 1;
-      } else {
-        ++len;
+      for (int it = 0; it <= (int)NIC_CW; ++it) {
+        const int32_t g = g0 + it * (int32_t)(4 * NIC_T);
+        if (it < (int)NIC_CW || tid < 4) s_px[tid + it * NIC_T] = (P >= 8 && g >= 0 && g + 4 <= Pi) ? r[it] : patch(g);
       }
     }
+    __syncthreads();
+    auto at = [&](uint32_t i) {  // i in [seg0 - 4, seg0 + NIC_SEG + 12)
+      const int32_t r = (int32_t)(i - seg0);
+      return (s_px[(r >> 2) + 1] >> (8 * (r & 3))) & 0xffu;
+    };
+    const uint32_t off_in = s_off;
+    const int32_t end_in = s_end;
+    const uint32_t c0 = seg0 + tid * (NIC_CW * 4);  // (may lie beyond P: then no bit is set)
+    const uint32_t* d = s_px + tid * NIC_CW + 1;    // d[k] = dword k of the chunk, k in [-1, NIC_CW + 1]
+
+    // ---- L and T bits of the chunk: bit j of the 3-word masks <-> pixel c0 - 4 + j ----
+    uint32_t EQ[3] = {0, 0, 0};
+#pragma unroll
+    for (int k = -1; k <= (int)NIC_CW; ++k) {  // eq flags, 4 per dword (bit 7 of byte b: px[4k+b] == px[4k+b+1])
+      const uint32_t a = d[k], x = a ^ __builtin_amdgcn_alignbyte(d[k + 1], a, 1);
+      const uint32_t ne = (x + 0x7f7f7f7fu) & 0x80808080u;
+      const int j = 4 * (k + 1);
+      EQ[j >> 5] |= (nic_nib(ne) ^ 0xfu) << (j & 31);
+    }
+    // multiword shifts by one / two positions (towards lower = the NEXT pixel moves onto this one)
+    auto next1 = [](const uint32_t (&m)[3], uint32_t (&r)[3]) {
+      r[0] = __builtin_amdgcn_alignbit(m[1], m[0], 1);
+      r[1] = __builtin_amdgcn_alignbit(m[2], m[1], 1);
+      r[2] = m[2] >> 1;
+    };
+    uint32_t Tm[3], Lm[3];
+    {
+      uint32_t e1[3], t[3], l1[3];
+      next1(EQ, e1);
+#pragma unroll
+      for (int w = 0; w < 3; ++w) t[w] = EQ[w] & e1[w];
+      // L = t | t(previous pixel) | t(two back)
+      Lm[0] = t[0] | t[0] << 1 | t[0] << 2;
+      Lm[1] = t[1] | __builtin_amdgcn_alignbit(t[1], t[0], 31) | __builtin_amdgcn_alignbit(t[1], t[0], 30);
+      Lm[2] = t[2] | __builtin_amdgcn_alignbit(t[2], t[1], 31) | __builtin_amdgcn_alignbit(t[2], t[1], 30);
+      next1(Lm, l1);
+#pragma unroll
+      for (int w = 0; w < 3; ++w) Tm[w] = (Lm[w] & ~EQ[w]) | (~Lm[w] & l1[w]);
+      // only the chunk's own pixels: j in [4, 4 + 4 * NIC_CW)
+      Tm[0] &= ~0xfu;
+      Tm[2] &= (1u << (4 + 4 * NIC_CW - 64)) - 1u;
+    }
+    if (P - 1 >= c0 && P - 1 - c0 < NIC_CW * 4) Tm[(P - 1 - c0 + 4) >> 5] |= 1u << ((P - 1 - c0 + 4) & 31u);
+    const int32_t jbase = (int32_t)c0 - 4;  // pixel of bit 0
+
+    // ---- previous token end before the chunk: max-scan of the chunks' last T bits ----
+    int32_t last_end = -1;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+      if (Tm[w]) last_end = jbase + 32 * w + 31 - __builtin_clz(Tm[w]);
+    int32_t mx = last_end;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int32_t t = __shfl_up(mx, o);
+      if (lane >= (uint32_t)o) mx = max(mx, t);
+    }
+    if (lane == 63) s_max[wave] = mx;
+    __syncthreads();
+    int32_t prev0 = end_in;
+    for (uint32_t w = 0; w < wave; ++w) prev0 = max(prev0, s_max[w]);
+    {
+      const int32_t t = __shfl_up(mx, 1);
+      if (lane > 0) prev0 = max(prev0, t);
+    }
+
+    // ---- sizes of the tokens that end in the chunk ----
+    uint32_t bytes = 0;
+    {
+      int32_t prev = prev0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        uint32_t m = Tm[w];
+        while (m) {
+          const uint32_t b = (uint32_t)__builtin_ctz(m);
+          m &= m - 1;
+          const int32_t e = jbase + 32 * w + (int32_t)b;
+          const uint32_t len = (uint32_t)(e - prev);
+          bytes += ((Lm[w] >> b) & 1u) ? nic_rep_bytes(len) : nic_lit_bytes(len);
+          prev = e;
+        }
+      }
+    }
+    uint32_t sum = bytes;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t t = (uint32_t)__shfl_up((int)sum, o);
+      if (lane >= (uint32_t)o) sum += t;
+    }
+    if (lane == 63) s_sum[wave] = sum;
+    __syncthreads();
+    uint32_t off = off_in + sum - bytes;
+    for (uint32_t w = 0; w < wave; ++w) off += s_sum[w];
+    if (off + bytes > p.stride) fits = false;
+
+    // ---- emission: into the wave's LDS slice, then one coalesced copy per wave ----
+    // (a wave whose tokens reach far back — a huge run cut into many pieces, a literal that
+    // began chunks ago — may exceed the slice: it writes straight to global memory instead)
+    uint32_t wave_off = off_in;
+    for (uint32_t w = 0; w < wave; ++w) wave_off += s_sum[w];
+    const uint32_t wave_bytes = s_sum[wave];
+    const bool staged = wave_bytes <= NIC_OUT;
+    const bool wave_fits = wave_off + wave_bytes <= p.stride;
+    if (bytes && (staged || fits)) {
+      uint8_t* o = staged ? s_out[wave] + (off - wave_off) : p.out + (size_t)f * p.stride + off;
+      // literal payload pixels: from the staged segment, or (a literal that began in an
+      // earlier segment) from the image in global memory
+      auto pixel = [&](uint32_t i) { return i + 4 >= seg0 ? at(i) : ((uint32_t)px[i] & 15u); };
+      int32_t prev = prev0;
+#pragma unroll
+      for (int w = 0; w < 3; ++w) {
+        uint32_t m = Tm[w];
+        while (m) {
+          const uint32_t b = (uint32_t)__builtin_ctz(m);
+          m &= m - 1;
+          const int32_t e = jbase + 32 * w + (int32_t)b;
+          const uint32_t len = (uint32_t)(e - prev);
+          if ((Lm[w] >> b) & 1u)
+            o = nic_emit_rep(o, at((uint32_t)e), len);
+          else
+            o = nic_emit_lit(o, pixel, (uint32_t)(prev + 1), len);
+          prev = e;
+        }
+      }
+    }
+    if (staged && wave_fits) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+      __builtin_amdgcn_wave_barrier();
+      uint8_t* dst = p.out + (size_t)f * p.stride + wave_off;
+      for (uint32_t j = lane; j < wave_bytes; j += 64) dst[j] = s_out[wave][j];
+    }
+    if (tid == NIC_T - 1) {  // carry to the next segment
+      s_off = off + bytes;
+      s_end = max(prev0, last_end);
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    p.sizes[f] = s_off;
+    if (s_off > p.stride) atomicOr(&p.status[2], 1u);
   }
 }
 
