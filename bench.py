@@ -174,6 +174,15 @@ def main():
     barrier()
     dtb = time.perf_counter() - t1
 
+    # tier C: + the frame codec main.cpp plugs into collect (nic::compress of image and median)
+    al.align(frames, n_total=n_total, blit=True, compress=True)
+    barrier()
+    t3 = time.perf_counter()
+    for _ in range(nb):
+        al.align(frames, n_total=n_total, blit=True, compress=True)
+    barrier()
+    dtc = time.perf_counter() - t3
+
     # host-fed rate: the same step with the frames coming from pinned host
     # memory over PCIe every time — reported beside the headline, never as `value`
     pinned = torch.from_numpy(frames_host).pin_memory()
@@ -200,10 +209,10 @@ def main():
     copy_gbs = 2.0 * frames.numel() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
     del pinned, stage
 
-    tmax = torch.tensor([dt, dtb, dth], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+    tmax = torch.tensor([dt, dtb, dth, dtc], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, dtb, dth = float(tmax[0]), float(tmax[1]), float(tmax[2])
+    dt, dtb, dth, dtc = (float(v) for v in tmax)
 
     if rank == 0:
         # algorithmic bytes of one kpe_main launch: SURVEY.md §8d's per-frame figure
@@ -231,6 +240,7 @@ def main():
                                                                    if world > 1 else "")},
             "offsets_bit_exact_vs_truth": exact,
             "frames_per_s_with_blit": n_total * nb / dtb,
+            "frames_per_s_with_blit_and_codec": n_total * nb / dtc,
             "frames_per_s_host_fed": n_total * nh / dth,
             "kernel_ms": dict(kpe_main=ms_kpe, **ms_parts),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

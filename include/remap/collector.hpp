@@ -14,12 +14,14 @@
 
 #include <list>
 #include <optional>
+#include <type_traits>
 #include <vector>
 
 #include "core.hpp"
 #include "device.hpp"
 #include "fragment.hpp"
 #include "grid.hpp"
+#include "nic.hpp"
 
 namespace remap::detail {
 
@@ -247,6 +249,14 @@ public:
       remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax * sizeof(rmx_desc),
                                    tstride * sizeof(rmx_desc), n),
                    ctx_, "rmx_download_2d");
+      // ---- frame blobs: nic::compression is run on the device for the whole block (two
+      // launches: images, medians); any other compressor is called per frame below ----
+      constexpr bool device_codec = std::is_same_v<std::decay_t<Comp>, nic::compression>;
+      std::vector<icd::compressed_t> pk_image, pk_median;
+      if constexpr (device_codec) {
+        pk_image = nic::detail::compress_device(ctx_, frames_.get<std::uint8_t>(), n, std::uint32_t(area));
+        pk_median = nic::detail::compress_device(ctx_, median_.get<std::uint8_t>(), n, std::uint32_t(area));
+      }
       // ---- device blit of the block, fragment by fragment (frc.hpp:129-135) ----
       for (std::uint32_t i = 0; i < n;) {
         std::uint32_t j = i;
@@ -264,8 +274,12 @@ public:
           image_type median{dim_, pixel_alloc_t{pool}};
           std::memcpy(median.data(), h_med_.data() + t * area, area);
           fgm::point_t p{h_pos_[2 * t], h_pos_[2 * t + 1]};
-          current_->frames_.emplace_back(
-              fgm::frame{block[t].number_, p, fgm::packed_data{comp(block[t].image_), comp(median)}});
+          if constexpr (device_codec)
+            current_->frames_.emplace_back(
+                fgm::frame{block[t].number_, p, fgm::packed_data{std::move(pk_image[t]), std::move(pk_median[t])}});
+          else
+            current_->frames_.emplace_back(
+                fgm::frame{block[t].number_, p, fgm::packed_data{comp(block[t].image_), comp(median)}});
           if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
           grid_type keys = remap::detail::table_to_grid<grid_type>(h_tab_.data() + std::size_t(t) * tstride, h_k_[t],
                                                                    allocator_t<char>{pool});

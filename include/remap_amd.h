@@ -219,7 +219,13 @@ uint32_t rmx_nic_bound(uint32_t pixels);
  * (offsets: n uint64 on the device, normally the exclusive scan of sizes).  Asynchronous. */
 int rmx_nic_pack(rmx_ctx* ctx, const uint8_t* blobs, uint32_t stride, const uint32_t* sizes,
                  const uint64_t* offsets, uint32_t n, uint8_t* packed);
-/* Synchronises; RMX_ERR_CAPACITY if a blob did not fit its stride since the last call. */
+/* nic::decompress (nic.hpp:103-164) of n blobs (packed + offsets[i], sizes[i] bytes, all on
+ * the device) into n images of `pixels` bytes.  A stream that is malformed or does not decode
+ * to exactly `pixels` pixels is reported by rmx_nic_status.  Asynchronous. */
+int rmx_nic_decompress_batch(rmx_ctx* ctx, const uint8_t* packed, const uint64_t* offsets,
+                             const uint32_t* sizes, uint32_t n, uint32_t pixels, uint8_t* images);
+/* Synchronises; RMX_ERR_CAPACITY if a blob did not fit its stride, RMX_ERR_ARG if a stream
+ * given to rmx_nic_decompress_batch was malformed, since the last call. */
 int rmx_nic_status(rmx_ctx* ctx);
 
 /* ---- introspection ----------------------------------------------------------------------- */

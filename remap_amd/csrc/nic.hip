@@ -311,4 +311,71 @@ __global__ __launch_bounds__(256) void nic_pack(NicPackParams p) {
   for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
+// nic::decompress (nic.hpp:103-164): one wave per image.  Tokens are variable-length, so the
+// parse is sequential — every lane walks the same token stream (uniform loads) — while the
+// pixels of each token are written by all lanes side by side.  Parallelism comes from the
+// batch (thousands of images in flight).
+struct NicDecParams {
+  const uint8_t* packed;
+  const uint64_t* offsets;
+  const uint32_t* sizes;
+  uint8_t* images;  // n x pixels
+  uint32_t* status;
+  uint32_t n, pixels;
+};
+__global__ __launch_bounds__(64) void nic_decompress(NicDecParams p) {
+  const uint32_t f = blockIdx.x, lane = threadIdx.x;
+  const uint8_t* src = p.packed + p.offsets[f];
+  const uint32_t size = p.sizes[f];
+  uint8_t* out = p.images + (size_t)f * p.pixels;
+  uint32_t i = 0, o = 0;
+  bool bad = false;
+  while (i < size) {
+    const uint32_t t = src[i];
+    if ((t & 0x80u) == 0) {  // REP
+      uint32_t len, nb = 0;
+      if ((t & 0x40u) == 0) {
+        len = (t >> 4) + 3;
+      } else {
+        nb = (t >> 4) & 3u;
+        if (i + nb >= size) {
+          bad = true;
+          break;
+        }
+        len = 0;
+        for (uint32_t b = 0; b < nb; ++b) len |= (uint32_t)src[i + 1 + b] << (8 * b);
+      }
+      i += 1 + nb;
+      if (o + len > p.pixels) {
+        bad = true;
+        break;
+      }
+      for (uint32_t j = lane; j < len; j += 64) out[o + j] = (uint8_t)(t & 15u);
+      o += len;
+    } else {  // LITERAL
+      uint32_t n = t & 0x3fu;
+      ++i;
+      if (t & 0x40u) {
+        if (i >= size) {
+          bad = true;
+          break;
+        }
+        n = (n << 8) + src[i++];
+      }
+      const uint32_t nbytes = (n + 1) >> 1;
+      if (i + nbytes > size || o + n > p.pixels) {
+        bad = true;
+        break;
+      }
+      for (uint32_t j = lane; j < n; j += 64) {
+        const uint32_t b = src[i + (j >> 1)];
+        out[o + j] = (uint8_t)((j & 1u) ? (b & 15u) : (b >> 4));
+      }
+      i += nbytes;
+      o += n;
+    }
+  }
+  if ((bad || o != p.pixels) && lane == 0) atomicOr(&p.status[2], 2u);  // malformed stream / wrong pixel count
+}
+
 }  // namespace rmx

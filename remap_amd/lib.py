@@ -32,7 +32,7 @@ SYMBOLS = [
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
-    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status",
+    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch",
 ]
 
 
@@ -111,6 +111,7 @@ def load():
     lib.rmx_nic_bound.restype = u32
     lib.rmx_nic_pack.argtypes = [vp, vp, u32, vp, vp, u32, vp]
     lib.rmx_nic_status.argtypes = [vp]
+    lib.rmx_nic_decompress_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     sz = C.c_size_t
     lib.rmx_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.rmx_free.argtypes = [vp, vp]
@@ -294,6 +295,21 @@ class Context:
                                         packed.data_ptr()), "rmx_nic_pack")
         self.sync()
         return packed, sz
+
+    def nic_decompress(self, packed, sizes, pixels):
+        """nic::decompress of len(sizes) blobs laid back to back in `packed` (uint8 CUDA tensor);
+        sizes: host int array.  Returns (n, pixels) uint8 CUDA tensor."""
+        t = self.torch
+        sz = np.ascontiguousarray(sizes, np.int64)
+        n = len(sz)
+        offs = np.concatenate([[0], np.cumsum(sz)[:-1]]).astype(np.int64)
+        doffs = t.from_numpy(offs).to(self.device)
+        dsz = t.from_numpy(sz.astype(np.int32)).to(self.device)
+        out = t.empty((n, pixels), dtype=t.uint8, device=self.device)
+        self._chk(self.lib.rmx_nic_decompress_batch(self.h, packed.data_ptr(), doffs.data_ptr(), dsz.data_ptr(), n,
+                                                    pixels, out.data_ptr()), "rmx_nic_decompress_batch")
+        self._chk(self.lib.rmx_nic_status(self.h), "rmx_nic_status")
+        return out
 
     # ---- fgm -------------------------------------------------------------------------------
     def fgm_extent(self, pos_host):

@@ -129,13 +129,16 @@ class Aligner:
             self._bufs[name] = b
         return b
 
-    def align(self, frames, n_total=None, blit=False, check=True):
+    def align(self, frames, n_total=None, blit=False, check=True, compress=False):
         """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
 
         Returns a dict with device tensors: median, desc, kcount (local block) and dxdy,
         matched, pos, frag for the WHOLE stream (identical on all ranks), plus `lo`, `hi`
         (this rank's frame range) and, if blit=True, `canvases` for the fragments that
-        have frames on this rank."""
+        have frames on this rank; if compress=True, `nic_image` and `nic_median`: the
+        nic::compress blobs of every local frame and median as (blobs (n, stride), sizes (n,))
+        device tensors — what collect stores with each frame (frc.hpp:118) behind main.cpp's
+        codec."""
         t = self.torch
         ctx = self.ctx
         n = frames.shape[0]
@@ -168,6 +171,11 @@ class Aligner:
             rc, fl = ctx.kpm_status()
             if rc:
                 raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
+        if compress:
+            out["nic_image"] = ctx.nic_compress(frames.reshape(n, -1), pack=False)
+            out["nic_median"] = ctx.nic_compress(median.reshape(n, -1), pack=False)
+            if check:
+                ctx._chk(ctx.lib.rmx_nic_status(ctx.h), "rmx_nic_status")
         if blit:
             out["canvases"] = self.blit(frames, pos, frag, lo, hi)
         return out

@@ -10,6 +10,7 @@
 
 #include "frc.hpp"
 #include "ful.hpp"
+#include "nic.hpp"
 #include "mpb.hpp"
 
 // same shape as main.cpp's file_feed (main.cpp:16-52), reading from one memory blob
@@ -101,6 +102,33 @@ static int run_ful(std::string const& in, std::string const& out) {
   return 0;
 }
 
+// collect with the reference's codec as Comp (main.cpp:113-125): nic::compression is batched
+// on the device by the collector; prints every frame's two blobs as hex for the test to compare
+static int run_nic(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob) {
+  frc::collector collector{dim};
+  auto cb = [](fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) {};
+  collector.collect(mem_feed{dim, blob}, nic::compression{}, cb);
+  auto fragments = collector.complete();
+  auto hex = [](icd::compressed_t const& v) {
+    std::string s;
+    char b[3];
+    for (auto x : v) {
+      std::snprintf(b, 3, "%02x", x);
+      s += b;
+    }
+    return s;
+  };
+  for (auto& f : fragments)
+    for (auto& fr : f.frames()) std::printf("blob %zu %s %s\n", fr.number_, hex(fr.data_.image_).c_str(), hex(fr.data_.median_).c_str());
+  // the single-image forms round-trip
+  sid::nat::dimg_t a{dim};
+  std::memcpy(a.data(), blob.data(), dim.area());
+  auto pk = nic::compress(a);
+  auto back = nic::compression{}(pk, dim);
+  std::printf("single %d %zu\n", int(std::memcmp(back.data(), a.data(), dim.area()) == 0), pk.size());
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -117,6 +145,7 @@ int main(int argc, char** argv) {
   std::vector<std::uint8_t> blob((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
   mrl::dimensions_t dim{W, H};
   if (argc > 4 && std::string(argv[4]) == "splice") return run_splice(dim, blob);
+  if (argc > 4 && std::string(argv[4]) == "nic") return run_nic(dim, blob);
 
   frc::collector collector{dim};
   std::size_t calls = 0, entries = 0, last_no = 0;

@@ -135,3 +135,23 @@ def test_ful_python_round_trip(gpu, tmp_path):
     ful.write(str(dst), frags, blobs)
     for k in range(int(g["nfiles"])):
         assert (dst / str(k)).read_bytes() == g[f"file{k}"].tobytes()
+
+
+def test_collect_with_nic_compression_blobs_match_oracle(gpu, tmp_path):
+    """frc::collector::collect with nic::compression (the codec main.cpp plugs in): the image
+    and median blob stored with every frame equal the oracle's nic streams, frame by frame."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(30, dens=120)
+    frames = frames.copy()
+    frames[11] = 6  # blank frame: a 76 800-pixel run, beyond the reference codec's uint16 domain
+    blob = tmp_path / "frames.bin"
+    frames.tofile(blob)
+    out = subprocess.run([exe, str(blob), "320", "240", "nic"], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().splitlines()
+    blobs = {int(l.split()[1]): l.split()[2:] for l in lines if l.startswith("blob ")}
+    assert sorted(blobs) == list(range(len(frames)))
+    for i, f in enumerate(frames):
+        med, _, _ = O.orc_kpe(f)
+        assert blobs[i][0] == O.orc_nic_compress(f).hex(), i
+        assert blobs[i][1] == O.orc_nic_compress(med).hex(), i
+    assert lines[-1].startswith("single 1 ")

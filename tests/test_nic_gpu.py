@@ -85,3 +85,32 @@ def test_nic_stride_too_small_is_reported(gpu):
     assert int(sizes[0]) > 64  # the true size is still reported
     assert ctx.lib.rmx_nic_status(ctx.h) == 0
     ctx.close()
+
+
+def test_nic_decompress_golden_streams_and_round_trip(gpu):
+    """rmx_nic_decompress_batch decodes the reference's own streams to their images, inverts
+    rmx_nic_compress_batch on whole frames, and reports a malformed stream."""
+    import torch
+
+    ctx = L.Context(16, 8, grid=(1, 1), overlap=0, kmax=64)
+    by_size = {}
+    for k, img, pk in nic_cases():
+        by_size.setdefault(img.size, []).append((img, pk))
+    for size, group in by_size.items():
+        packed = torch.from_numpy(np.frombuffer(b"".join(g[1] for g in group), np.uint8).copy()).cuda()
+        out = ctx.nic_decompress(packed, [len(g[1]) for g in group], size).cpu().numpy()
+        for row, (img, _) in zip(out, group):
+            assert np.array_equal(row, img.reshape(-1))
+    fr = np.concatenate([scroller_v1(6, dens=200)[0], scroller_v1(3, dens=40)[0],
+                         np.full((1, 240, 320), 6, np.uint8),
+                         np.random.default_rng(2).integers(0, 16, size=(1, 240, 320), dtype=np.uint8)])
+    d = torch.from_numpy(fr).cuda()
+    packed, sizes = ctx.nic_compress(d.reshape(len(fr), -1))
+    back = ctx.nic_decompress(packed, sizes, 320 * 240)
+    assert torch.equal(back, d.reshape(len(fr), -1))
+    # truncated stream / wrong pixel count -> RMX_ERR_ARG
+    with pytest.raises(L.RemapError):
+        ctx.nic_decompress(packed, [int(sizes[0]) - 1], 320 * 240)
+    with pytest.raises(L.RemapError):
+        ctx.nic_decompress(packed, [int(sizes[0])], 320 * 240 - 5)
+    ctx.close()
