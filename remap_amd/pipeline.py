@@ -10,10 +10,11 @@ Reference loop (sequential, frc.hpp:97-122)      this driver (batched, per rank)
 Multi-GPU: the stream is cut into contiguous frame blocks, one per rank.
 kpe needs no communication.  kpm needs, per rank, the descriptor table of the frame just
 before its block: the boundary tables (last frame of every rank, kmax*18 B + count) are
-exchanged with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests).  The
-per-frame (matched, dx, dy) triples are all-gathered (9 B/frame) and every rank runs the
-segmented scan over the whole stream, so positions and fragment ids are global and
-identical on all ranks.  No other data-path collective exists.
+exchanged with ONE all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests).  Positions
+and fragment ids are a segmented scan of the per-frame offsets: every rank scans its own
+block and the blocks are stitched with a 16-byte summary per rank (second tiny all-gather),
+so a rank never touches another rank's per-frame data to align its frames.  Whole-stream
+positions (12 B/frame) are gathered only to size fragment canvases.
 """
 from __future__ import annotations
 
@@ -21,7 +22,8 @@ import numpy as np
 
 from . import lib as L
 
-__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets", "sum_subcanvases"]
+__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets", "sum_subcanvases",
+           "fold_block_summaries", "gather_block_rows"]
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -84,6 +86,34 @@ def gather_offsets(dxdy, matched, counts, dist=None, group=None):
     return cat[:, :2].contiguous(), cat[:, 2].to(torch.uint8).contiguous()
 
 
+def fold_block_summaries(summaries, rank):
+    """Carry into rank `rank`'s block from the scan summaries of the blocks before it.
+
+    summaries: (world, 4) integers per block [has a fragment start, x, y, starts]: position of
+    the block's last frame relative to its last fragment start (or to the block's begin if it
+    has none), and the number of fragment starts in it (frc.hpp:109-115).  Returns
+    ((x, y), fragments) = position and fragment id of the frame just before the block."""
+    ax = ay = ac = 0
+    for q in range(rank):
+        r, x, y, c = (int(v) for v in summaries[q])
+        ax, ay = (x, y) if r else (ax + x, ay + y)
+        ac += c
+    return (ax, ay), ac
+
+
+def gather_block_rows(rows, counts, dist, group=None):
+    """All-gather per-frame rows (n_local, k) int32 of every rank's block into stream order
+    (blocks may differ by one frame -> padded gather)."""
+    import torch
+
+    world = dist.get_world_size(group)
+    m = max(counts)
+    pack = torch.zeros((m, rows.shape[1]), dtype=torch.int32, device=rows.device)
+    pack[: rows.shape[0]] = rows
+    allp = _all_gather_flat(pack, world, dist, group).view(world, m, rows.shape[1])
+    return torch.cat([allp[r, : counts[r]] for r in range(world)])
+
+
 def sum_subcanvases(sub, zero, gbox, dist, group=None, device=None):
     """Bin-wise sum modulo 2^16 of every rank's sub-canvas of ONE fragment (fgm.hpp:99-113).
 
@@ -132,10 +162,13 @@ class Aligner:
     def align(self, frames, n_total=None, blit=False, check=True, compress=False):
         """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
 
-        Returns a dict with device tensors: median, desc, kcount (local block) and dxdy,
-        matched, pos, frag for the WHOLE stream (identical on all ranks), plus `lo`, `hi`
-        (this rank's frame range) and, if blit=True, `canvases` for the fragments that
-        have frames on this rank; if compress=True, `nic_image` and `nic_median`: the
+        Returns a dict with device tensors for the LOCAL block (frames lo..hi of the stream):
+        median, desc, kcount, dxdy, matched and pos, frag in GLOBAL canvas coordinates /
+        fragment numbering, plus `lo`, `hi`, `nfrag` (fragments of the whole stream).  With
+        several ranks the global values come from a 16-byte scan summary per rank (ONE tiny
+        all-gather), not from gathering every frame's offset; `pos_all` / `frag_all` (whole
+        stream, identical on all ranks) are gathered only when canvases are asked for.  If
+        blit=True, `canvases` for the fragments that have frames on this rank; if compress=True, `nic_image` and `nic_median`: the
         nic::compress blobs of every local frame and median as (blobs (n, stride), sizes (n,))
         device tensors — what collect stores with each frame (frc.hpp:118) behind main.cpp's
         codec."""
@@ -156,13 +189,20 @@ class Aligner:
             if self.rank > 0:
                 halo = (tabs[self.rank - 1].contiguous(), cnts[self.rank - 1:self.rank].contiguous())
         dxdy, matched = ctx.kpm_seq(desc, kcount, halo=halo)
+        pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=(self.rank == 0))  # synchronises
+        nfrag = carry[1] + 1
         if self.world > 1:
-            counts = [shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0]
-                      for r in range(self.world)]
-            dxdy, matched = gather_offsets(dxdy, matched, counts, self.dist, self.group)
-        pos, frag, carry = ctx.frc_scan(dxdy, matched)  # synchronises
+            # this block's summary: did a fragment start in it, where its last frame sits
+            # relative to that start (or to the block's begin), how many starts
+            mine = t.tensor([[int(carry[1] > 0 or self.rank == 0), carry[0][0], carry[0][1], carry[1]]],
+                            dtype=t.int32, device=frames.device)
+            summ = _all_gather_flat(mine, self.world, self.dist, self.group).cpu().numpy()
+            carry_in = fold_block_summaries(summ, self.rank)
+            nfrag = int(summ[:, 3].sum()) + 1
+            if self.rank > 0:
+                pos, frag, _ = ctx.frc_scan(dxdy, matched, first_is_start=False, carry=carry_in)
         out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
-                   lo=lo, hi=hi, nfrag=carry[1] + 1)
+                   lo=lo, hi=hi, nfrag=nfrag, n_total=n_total)
         if check:
             rc, _ = ctx.kpe_status(want_max=False)
             if rc:
@@ -177,8 +217,25 @@ class Aligner:
             if check:
                 ctx._chk(ctx.lib.rmx_nic_status(ctx.h), "rmx_nic_status")
         if blit:
-            out["canvases"] = self.blit(frames, pos, frag, lo, hi)
+            self.gather_positions(out)
+            out["canvases"] = self.blit(frames, out["pos_all"], out["frag_all"], lo, hi)
         return out
+
+    def gather_positions(self, out):
+        """pos_all / frag_all: positions and fragment ids of the WHOLE stream on every rank
+        (12 B per frame, one all-gather) — needed to size fragment canvases, not to align."""
+        if "pos_all" in out:
+            return
+        if self.world == 1:
+            out["pos_all"], out["frag_all"] = out["pos"], out["frag"]
+            return
+        t = self.torch
+        n_total = out["n_total"]
+        counts = [shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0]
+                  for r in range(self.world)]
+        rows = t.cat([out["pos"], out["frag"].to(t.int32)[:, None]], dim=1).contiguous()
+        allr = gather_block_rows(rows, counts, self.dist, self.group)
+        out["pos_all"], out["frag_all"] = allr[:, :2].contiguous(), allr[:, 2].contiguous()
 
     def blit(self, frames, pos, frag, lo, hi):
         """fgm::fragment::blit of this rank's frames.  For every fragment with frames on this
@@ -223,11 +280,12 @@ class Aligner:
         from .splice import Fragment
 
         t = self.torch
+        self.gather_positions(out)
         canv = out.get("canvases")
         if canv is None:
-            canv = self.blit(frames, out["pos"], out["frag"], out["lo"], out["hi"])
-        pos_h = out["pos"].cpu().numpy()
-        frag_h = out["frag"].cpu().numpy()
+            canv = self.blit(frames, out["pos_all"], out["frag_all"], out["lo"], out["hi"])
+        pos_h = out["pos_all"].cpu().numpy()
+        frag_h = out["frag_all"].cpu().numpy()
         result = []
         for fid in range(int(out["nfrag"])):
             sel = np.nonzero(frag_h == fid)[0]

@@ -104,3 +104,46 @@ def test_two_rank_gloo_equals_single_process():
         assert np.array_equal(gd, o["dxdy"]), rank
         assert np.array_equal(gm, o["matched"]), rank
     assert o["matched"][21] == 0 and o["matched"][22] == 0 and o["matched"][20] == 1
+
+
+def _scan(dxdy, matched, first_is_start, carry=((0, 0), 0)):
+    """frc.hpp:109-115 on the host: positions, fragment ids, carry-out."""
+    (x, y), c = carry
+    pos, frag = [], []
+    for i in range(len(matched)):
+        if (i == 0 and first_is_start) or not matched[i]:
+            c += 0 if (i == 0 and first_is_start) else 1
+            x = y = 0
+        else:
+            x += int(dxdy[i][0])
+            y += int(dxdy[i][1])
+        pos.append((x, y))
+        frag.append(c)
+    return np.array(pos).reshape(-1, 2), np.array(frag), ((x, y), c)
+
+
+def test_block_summaries_stitch_to_the_global_scan():
+    """fold_block_summaries: per-rank scans + 16-byte summaries reproduce the scan of the whole
+    stream (any number of ranks, blocks without any fragment start, starts at block edges)."""
+    from remap_amd.pipeline import fold_block_summaries
+
+    rng = np.random.default_rng(12)
+    for trial in range(40):
+        n, world = int(rng.integers(5, 200)), int(rng.integers(1, 9))
+        p_break = float(rng.choice([0.0, 0.02, 0.3]))
+        matched = (rng.random(n) >= p_break).astype(np.uint8)
+        dxdy = rng.integers(-4, 5, size=(n, 2))
+        gpos, gfrag, gcarry = _scan(dxdy, matched, True)
+        summ = []
+        for r in range(world):
+            lo, hi = shard_range(n, r, world)
+            _, _, ((x, y), c) = _scan(dxdy[lo:hi], matched[lo:hi], r == 0)
+            summ.append([int(c > 0 or r == 0), x, y, c])
+        assert sum(s[3] for s in summ) == gcarry[1]
+        for r in range(world):
+            lo, hi = shard_range(n, r, world)
+            if hi == lo:
+                continue
+            carry = fold_block_summaries(summ, r)
+            pos, frag, _ = _scan(dxdy[lo:hi], matched[lo:hi], r == 0, carry if r else ((0, 0), 0))
+            assert np.array_equal(pos, gpos[lo:hi]) and np.array_equal(frag, gfrag[lo:hi]), (trial, r)
