@@ -157,7 +157,9 @@ def main():
                  and out["nfrag"] == 1)
     ktot = int(out["kcount"].sum().item())
 
-    al.ctx.set_timing(True)
+    # the timed region records HIP events around kpe_main only (an event pair costs ~10 us of
+    # stream time per launch); the other kernels are timed in a separate, untimed pass below
+    al.ctx.set_timing(2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -166,8 +168,11 @@ def main():
     dt = time.perf_counter() - t0
     ms_kpe = al.ctx.kernel_ms("kpe_main")          # average per launch
     launches_per_step = al.ctx.kernel_launches("kpe_main") / max(1, args.steps)
-    # per-step totals of the other kernels (kpm_build / kpm_match run two instances each)
-    ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / max(1, args.steps)
+    al.ctx.set_timing(True)
+    for _ in range(3):
+        al.align(frames, n_total=n_total)
+    # per-step totals of the other kernels (kpm_build / kpm_match run several instances each)
+    ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3
                 for k in ("kpe_finish", "kpe_table", "kpm_build", "kpm_match")}
     al.ctx.set_timing(False)
 

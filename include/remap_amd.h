@@ -238,7 +238,9 @@ void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
  * synchronisation while recording).  rmx_set_timing(ctx, 1) opens a measurement window (and
  * drops earlier samples); rmx_last_kernel_ms synchronises the stream and returns the AVERAGE
  * duration in milliseconds of `kernel` ("kpe_main", "kpe_finish", "kpe_table", "kpm_build", "kpm_match",
- * "fgm_blit") over the launches of the window (0 if none). */
+ * "fgm_blit", "nic_compress") over the launches of the window (0 if none).  An event pair
+ * costs ~10 us of stream time per launch on this hardware: enabled = 2 records only
+ * "kpe_main" (what bench.py uses inside its timed region), 0 switches recording off. */
 int rmx_set_timing(rmx_ctx* ctx, int enabled);
 int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms);
 /* Number of launches of `kernel` recorded in the current window (rmx_kpe_batch walks a big

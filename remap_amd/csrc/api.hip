@@ -46,7 +46,7 @@ struct rmx_ctx {
   size_t ws_bytes = 0;
   // timing: HIP event pairs recorded on the context stream around each kernel launch,
   // resolved (averaged) only when rmx_last_kernel_ms is called — no host sync in between
-  bool timing = false;
+  int timing = 0;  // 0 off, 1 every kernel, 2 kpe_main only (the roofline kernel)
   struct Track {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -107,7 +107,7 @@ struct Timer {
   rmx_ctx::Track* t;
   std::pair<hipEvent_t, hipEvent_t>* p = nullptr;
   Timer(rmx_ctx* c_, rmx_ctx::Track* t_) : c(c_), t(t_) {
-    if (!c->timing) return;
+    if (!c->timing || (c->timing == 2 && t != &c->ms_kpe)) return;
     if (t->used == t->ev.size()) {
       hipEvent_t a = nullptr, b = nullptr;
       if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
@@ -212,7 +212,7 @@ size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx) { return ctx ? ctx->ws_bytes 
 
 int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   if (!ctx) return RMX_ERR_ARG;
-  ctx->timing = enabled != 0;
+  ctx->timing = enabled == 2 ? 2 : (enabled != 0);
   // (re)start a measurement window: forget the pairs recorded so far
   RMX_HIP(hipStreamSynchronize(ctx->stream));
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic}) t->used = 0;

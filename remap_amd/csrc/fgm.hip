@@ -12,9 +12,10 @@ struct ScanParams {
   const uint8_t* matched;
   int32_t* pos;
   uint32_t* frag;
-  int32_t* carry;  // device: [0..1] position, [2] fragment id (in/out)
+  int32_t* carry;  // device: [0..1] position, [2] fragment id (out)
   uint32_t n;
   uint32_t first_is_start;
+  int32_t carry_in[3];  // the carry on entry (by value: no upload)
 };
 
 // Summary of a run of frames: did it contain a fragment start, the position offset since the
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
   if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
   if (tid == 0) {
-    ScanSeg acc{0, p.carry[0], p.carry[1], p.carry[2]};
+    ScanSeg acc{0, p.carry_in[0], p.carry_in[1], p.carry_in[2]};
     for (uint32_t w = 0; w < 16; ++w) {
       const ScanSeg t = s_wave[w];
       s_wave[w] = acc;

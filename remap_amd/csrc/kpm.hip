@@ -434,7 +434,7 @@ __device__ inline void bitonic_sort_u32(uint32_t* a, uint32_t n2) {
 // General instance (one workgroup per frame, regions one after the other).  It runs after
 // kpm_build_small and takes only the frames that kernel marked in `needs_large`.
 template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
-__global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large) {
+__device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const uint32_t* needs_large, uint32_t fslot) {
   __shared__ uint16_t ent[KC];       // scan indices of the region's entries, scan order
   __shared__ uint16_t slot_of[KC];   // hash slot of entry i
   __shared__ uint16_t gid_of[KC];    // rank of a group's first entry -> group id
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
   __shared__ uint32_t scan_scratch[8];
   __shared__ uint32_t s_w2, s_w1;
 
-  const uint32_t fslot = blockIdx.x;  // 0..n-1 frames of the batch, n = halo
+  // fslot: 0..n-1 frames of the batch, n = halo
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
@@ -574,7 +574,12 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
 // only the frames marked in `needs_large`.
 constexpr uint32_t KS_RC = 64;  // entries per region
 
-__global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_t* needs_large) {
+__global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_t* needs_large, uint32_t* work, uint32_t work_stride) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the matcher's work lists (used by later launches)
+    work[0] = 0;
+    work[work_stride] = 0;
+    work[2 * work_stride] = 0;
+  }
   __shared__ uint16_t ent[8][KS_RC];
   __shared__ uint32_t htl[8][2 * KS_RC];
   __shared__ uint64_t hg[8][KS_RC];
@@ -741,14 +746,13 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint3
 // RC = entries per region the instance holds (256: 70 KB of LDS, two workgroups per CU;
 // 512: 139 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
 template <uint32_t RC, uint32_t TIN>
-__global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier) {
+__device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, uint32_t* tier, uint32_t fslot) {
   __shared__ uint16_t ent[8][RC], slot_of[8][RC], gid_of[8][RC], seq_a[8][RC], seq_b[8][RC];
   __shared__ uint32_t htl[8][2 * RC], keys[8][RC], bmin[8][RC == 256 ? 257 : 541];
   __shared__ uint64_t hg[8][RC];
   __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big;
 
-  const uint32_t fslot = blockIdx.x;
   if (tier[fslot] != TIN) return;  // uniform: built already, or not yet examined
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
@@ -897,6 +901,24 @@ __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32
   wbar();
   // keys[r] is free again: iteration order of this region's code map
   umap_order_par<64, RC>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
+}
+
+// The instances behind kpm_build_small are launched on a FIXED grid that strides over the
+// frames: on a stream where kpm_build_small builds everything they cost a few microseconds
+// instead of a launch of n mostly empty workgroups each.
+template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
+__global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large, uint32_t nslots) {
+  for (uint32_t fslot = blockIdx.x; fslot < nslots; fslot += gridDim.x) {
+    kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot);
+    __syncthreads();  // LDS is reused by the next frame
+  }
+}
+template <uint32_t RC, uint32_t TIN>
+__global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
+  for (uint32_t fslot = blockIdx.x; fslot < nslots; fslot += gridDim.x) {
+    kpm_build_medium_frame<RC, TIN>(p, tier, fslot);
+    __syncthreads();
+  }
 }
 
 // ---- matching --------------------------------------------------------------------------------------

@@ -179,6 +179,7 @@ class Context:
         self._chk(self.lib.rmx_sync(self.h), "rmx_sync")
 
     def set_timing(self, on=True):
+        """True / 1: HIP event pairs around every kernel; 2: around kpe_main only; False: off."""
         self.lib.rmx_set_timing(self.h, int(on))
 
     def kernel_ms(self, name):
