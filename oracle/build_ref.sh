@@ -13,6 +13,7 @@
 #           kpe.hpp:55   _mm256_castsi128_si256({})      -> (_mm_setzero_si128())
 #           kpe.hpp:381-394  three dead members (never called) deleted
 #           all.hpp:158  `= {n}` through an explicit ctor -> `= memory_pool{n}`
+# Tier 2  libref_fdf.so    : + fdf/fde/cte (foreground filter), see the end of this script.
 set -euo pipefail
 here="$(cd "$(dirname "$0")" && pwd)"
 ref="${REMAP_REFERENCE:-/root/reference}/src"
@@ -41,3 +42,16 @@ n=$(diff <(cat "$ref/kpe.hpp" "$ref/all.hpp") <(cat "$tmp/kpe.hpp" "$tmp/all.hpp
 if [ "$n" != "20" ]; then echo "build_ref: unexpected patch size ($n changed lines)"; exit 1; fi
 $CXX $FLAGS -I"$tmp" "$here/ref_harness_full.cpp" -o "$out/libref_full.so"
 echo "build_ref: built $out/libref_full.so (tier 2, patched temporary copy, removed)"
+
+# ---- tier 2, foreground filter (fdf/fde/cte): one more spelling patch, AVX-512VL/BW flags ------
+#   fde.hpp:10   <intrin.h>  -> <immintrin.h>
+# Built only where the host CPU can run it; loaded only by tests / make_golden on this machine.
+if grep -q avx512bw /proc/cpuinfo && grep -q avx512vl /proc/cpuinfo; then
+  sed -i '10s/#include <intrin.h>/#include <immintrin.h>/' "$tmp/fde.hpp"
+  n=$(diff "$ref/fde.hpp" "$tmp/fde.hpp" | grep -c '^[<>]' || true)
+  if [ "$n" != "2" ]; then echo "build_ref: unexpected fde.hpp patch size ($n changed lines)"; exit 1; fi
+  $CXX $FLAGS -mavx512vl -mavx512bw -Wl,-Bsymbolic -I"$tmp" "$here/ref_harness_fdf.cpp" -o "$out/libref_fdf.so"
+  echo "build_ref: built $out/libref_fdf.so (tier 2, foreground filter)"
+else
+  echo "build_ref: no AVX-512VL/BW on this host - libref_fdf.so not built"
+fi

@@ -13,6 +13,7 @@ checksum of the generated input) and expected outputs only — never reference s
     python oracle/make_golden.py          # rewrites tests/golden/
     python oracle/make_golden.py ful      # only the fragment-file fixture (ful_case.npz)
     python oracle/make_golden.py nic      # only the codec fixture (nic_cases.npz)
+    python oracle/make_golden.py fdf      # only the foreground-filter fixture (fdf_cases.npz)
 """
 from __future__ import annotations
 
@@ -130,7 +131,43 @@ def golden_nic():
     print("nic fixture:", len(cases), "cases,", int(out["sizes"].sum()), "compressed bytes")
 
 
+def fdf_inputs():
+    """Streams of the fdf fixture (generator parameters only; remap_amd/synth.py is committed).
+    Widths are multiples of 32: fde.hpp's aligned 256-bit loads need it under g++."""
+    from remap_amd.synth import with_sprites
+
+    a, _ = scroller_v1(24, width=128, height=64, dens=30)
+    a = with_sprites(a, n_sprites=3, size=11, seed=5)
+    a[10] = 6  # blank frame: fragment break
+    b, _, _ = rooms_v1(60, width=128, height=96, n_rooms=2, dens=40, seed=3)
+    b = with_sprites(b, n_sprites=2, size=9, seed=9)
+    c, _ = scroller_v1(8, width=320, height=240, dens=200)
+    c = with_sprites(c, n_sprites=3, size=15, seed=1)
+    return [a, b, c]
+
+
+def golden_fdf():
+    """frc collect + fdf::filter of the reference (fdf.hpp:40-89, tier 2 / libref_fdf.so)."""
+    assert O.ref_fdf_lib() is not None, "run oracle/build_ref.sh first (needs AVX-512VL/BW)"
+    out = {}
+    for k, fr in enumerate(fdf_inputs()):
+        r = O.ref_fdf(fr)
+        out[f"input_sha256_{k}"] = np.frombuffer(bytes.fromhex(sha(fr)), np.uint8)
+        out[f"shape{k}"] = np.array(fr.shape)
+        out[f"masks{k}"] = np.packbits(r["masks"] != 0)
+        out[f"ncontours{k}"] = r["ncontours"]
+        out[f"frag{k}"] = r["frag"]
+        out[f"dims{k}"] = r["dims"]
+        out[f"canvas_sum{k}"] = r["canvas_sum"]
+        print("fdf case", k, fr.shape, "fragments", r["nfrag"], "mask pixels", int((r["masks"] != 0).sum()),
+              "contours/frame", float(r["ncontours"].mean()))
+    out["ncases"] = np.array(len(fdf_inputs()))
+    np.savez_compressed(os.path.join(OUT, "fdf_cases.npz"), **out)
+
+
 def main():
+    if sys.argv[1:] == ["fdf"]:
+        return golden_fdf()
     if sys.argv[1:] == ["ful"]:
         return golden_ful()
     if sys.argv[1:] == ["nic"]:
@@ -309,6 +346,8 @@ def main():
                         canvas_sum=sp["canvas_sum"])
     golden_ful()
     golden_nic()
+    if O.ref_fdf_lib() is not None:
+        golden_fdf()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, f"({tot / 1024:.0f} KiB)")
     print("fgs: collected", sp["ncollected"], "-> spliced", sp["nfrag"], "dims", sp["dims"].tolist())

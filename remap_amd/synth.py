@@ -113,3 +113,21 @@ def rooms_v1(n_frames: int, width: int = 320, height: int = 240, n_rooms: int = 
         frames[f] = 6
         f += 1
     return frames, room_id, cam_xy
+
+
+def with_sprites(frames, n_sprites=2, size=9, seed=5):
+    """Overlay small multi-coloured sprites that move on the SCREEN (not with the world): the
+    foreground fdf::filter is there to remove.  Sprite k follows a Lissajous path; its pattern
+    is a fixed random size x size block with a few transparent pixels."""
+    rng = np.random.default_rng(seed)
+    out = frames.copy()
+    n, H, W = frames.shape
+    pats = [rng.integers(0, 16, size=(size, size), dtype=np.uint8) for _ in range(n_sprites)]
+    holes = [rng.random((size, size)) < 0.15 for _ in range(n_sprites)]
+    for i in range(n):
+        for k in range(n_sprites):
+            cx = int((W - size - 8) * (0.5 + 0.45 * np.sin(0.07 * i * (k + 1) + k))) + 4
+            cy = int((H - size - 8) * (0.5 + 0.45 * np.cos(0.05 * i * (k + 2) + 2 * k))) + 4
+            blk = out[i, cy:cy + size, cx:cx + size]
+            blk[~holes[k]] = pats[k][~holes[k]]
+    return out

@@ -387,3 +387,78 @@ def ref_ful_read(directory):
     n = C.c_uint32()
     vec = _RefFulVector(lib, lib.ref_ful_read(str(directory).encode(), C.byref(n)))
     return [RefFragmentView(lib, lib.ref_ful_get(vec.h, i), vec) for i in range(n.value)]
+
+
+def ref_fdf_lib():
+    if "f" not in _ref:
+        lib = _load_ref("libref_fdf.so")
+        if lib is not None:
+            lib.ref_fdf.restype = C.c_uint32
+        _ref["f"] = lib
+    return _ref["f"]
+
+
+def ref_fdf(frames, want=0):
+    """frc collect + fdf::filter of the reference (fdf.hpp:40-89).  Returns per-frame masks,
+    kept-contour counts, fragment index; per fragment dims and canvas checksum; dots of `want`."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, H, W = frames.shape
+    masks = np.zeros((n, H, W), np.uint8)
+    ncont = np.zeros(n, np.uint32)
+    frag = np.zeros(n, np.uint32)
+    dims = np.zeros((n, 2), np.uint32)
+    csum = np.zeros(n, np.uint64)
+    cap = 64 * 1024 * 1024
+    dots = np.zeros(cap, np.uint16)
+    nf = ref_fdf_lib().ref_fdf(ptr(frames), n, W, H, ptr(masks), ptr(ncont), ptr(frag), ptr(dims), ptr(csum), want,
+                               ptr(dots), C.c_uint64(cap))
+    w, h = int(dims[want, 0]), int(dims[want, 1])
+    return dict(nfrag=nf, masks=masks, ncontours=ncont, frag=frag, dims=dims[:nf].copy(), canvas_sum=csum[:nf].copy(),
+                dots=dots[: w * h * 16].reshape(h, w, 16).copy())
+
+
+def orc_fdf_mask(bg, bpos, frame, median):
+    bg = np.ascontiguousarray(bg, np.uint8)
+    frame = np.ascontiguousarray(frame, np.uint8)
+    median = np.ascontiguousarray(median, np.uint8)
+    H, W = frame.shape
+    mask = np.zeros((H, W), np.uint8)
+    lib = oracle()
+    lib.orc_fdf_mask.restype = C.c_uint32
+    k = lib.orc_fdf_mask(ptr(bg), bg.shape[1], bg.shape[0], int(bpos[0]), int(bpos[1]), ptr(frame), ptr(median), W, H,
+                         ptr(mask))
+    return mask, int(k)
+
+
+def orc_fgm_blit_masked(canvas, zero, img, mask, pos):
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(mask, np.uint8)
+    H, W = img.shape
+    oracle().orc_fgm_blit_masked(ptr(canvas), canvas.shape[1], canvas.shape[0], int(zero[0]), int(zero[1]), ptr(img),
+                                 ptr(mask), W, H, int(pos[0]), int(pos[1]))
+
+
+def orc_fdf_filter(frames):
+    """collect (oracle) + fdf::filter restated: per-frame masks, kept counts, filtered canvases."""
+    frames = np.ascontiguousarray(frames, np.uint8)
+    n, H, W = frames.shape
+    o = orc_frc(frames)
+    nfrag = int(o["frag"].max()) + 1
+    masks = np.zeros((n, H, W), np.uint8)
+    ncont = np.zeros(n, np.uint32)
+    canvases = []
+    for f in range(nfrag):
+        idx = np.nonzero(o["frag"] == f)[0]
+        cw, ch, zx, zy = orc_fgm_extent(o["pos"][idx], W, H)
+        can = np.zeros((ch, cw, 16), np.uint16)
+        for i in idx:
+            orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
+        bg, _ = orc_fgm_blend(can)
+        res = np.zeros((ch, cw, 16), np.uint16)
+        for i in idx:
+            med, _, _ = orc_kpe(frames[i])
+            p = o["pos"][i]
+            masks[i], ncont[i] = orc_fdf_mask(bg, (p[0] - zx, p[1] - zy), frames[i], med)
+            orc_fgm_blit_masked(res, (zx, zy), frames[i], masks[i], p)
+        canvases.append(res)
+    return dict(nfrag=nfrag, masks=masks, ncontours=ncont, frag=o["frag"], canvases=canvases)

@@ -239,3 +239,34 @@ def test_nic_beyond_the_reference_domain_round_trips():
         d, cnt = O.orc_nic_decompress(pk, x.size)
         assert cnt == x.size and np.array_equal(d, x)
     assert O.orc_nic_compress(blank).hex() == "66ffff66012c"  # 65535 + 11265
+
+
+def fdf_streams():
+    """The streams of tests/golden/fdf_cases.npz, regenerated from the committed generator."""
+    from remap_amd.synth import rooms_v1, with_sprites
+
+    a, _ = scroller_v1(24, width=128, height=64, dens=30)
+    a = with_sprites(a, n_sprites=3, size=11, seed=5)
+    a[10] = 6
+    b, _, _ = rooms_v1(60, width=128, height=96, n_rooms=2, dens=40, seed=3)
+    b = with_sprites(b, n_sprites=2, size=9, seed=9)
+    c, _ = scroller_v1(8, width=320, height=240, dens=200)
+    c = with_sprites(c, n_sprites=3, size=15, seed=1)
+    return [a, b, c]
+
+
+def test_fdf_cases():
+    """oracle collect + foreground filter == the reference's fdf::filter: per-frame masks,
+    kept contours, filtered canvases (checksums)."""
+    g = np.load(os.path.join(G, "fdf_cases.npz"))
+    for k, fr in enumerate(fdf_streams()):
+        assert hashlib.sha256(fr.tobytes()).digest() == g[f"input_sha256_{k}"].tobytes()
+        o = O.orc_fdf_filter(fr)
+        n, H, W = fr.shape
+        want = np.unpackbits(g[f"masks{k}"])[: n * H * W].reshape(n, H, W)
+        assert np.array_equal(o["masks"] != 0, want != 0), k
+        assert np.array_equal(o["ncontours"], g[f"ncontours{k}"]) and np.array_equal(o["frag"], g[f"frag{k}"]), k
+        assert o["nfrag"] == len(g[f"dims{k}"])
+        for f, can in enumerate(o["canvases"]):
+            assert [can.shape[1], can.shape[0]] == g[f"dims{k}"][f].tolist()
+            assert poly_sum(can) == int(g[f"canvas_sum{k}"][f]), (k, f)
