@@ -201,6 +201,25 @@ int rmx_kpm_cell_pairs(rmx_ctx* ctx, const rmx_desc* const* tables,
                        const uint32_t* dims, uint32_t nfrag, const uint32_t* pairs,
                        uint32_t npairs, uint32_t cell_w, uint32_t cell_h, rmx_vote* votes);
 
+/* ---- fdf: foreground filtering of a fragment's frames -------------------------------------- */
+
+/* fdf::filter for n frames of ONE fragment (fdf.hpp:40-89): per frame fde::extractor::extract
+ * (fde.hpp:95-120 — contours of equal median colour, cte.hpp:64-166, seeded where the frame
+ * differs from the background, kept up to W*H/5 pixels), fde::mask (fde.hpp:125-146) and the
+ * masked fragment::blit (fgm.hpp:71-86).
+ *   bg       : background image, bw x bh bytes (device): rmx_fgm_blend of the fragment's canvas
+ *   frames, medians : n images of the context's size (device)
+ *   pos      : n x 2 int32 (device): frame position inside the background (position - zero)
+ *   masks    : n x W x H bytes out (device): 1 = foreground
+ *   ncontours: n uint32 out (device) or NULL: contours kept per frame
+ *   canvas   : bh x bw x 16 uint16 (device) or NULL: receives the masked blit (added)
+ * Asynchronous.  rmx_fdf_status synchronises; RMX_ERR_CAPACITY if a frame had more than 4 096
+ * kept contours since the last call. */
+int rmx_fdf_filter_batch(rmx_ctx* ctx, const uint8_t* bg, uint32_t bw, uint32_t bh,
+                         const uint8_t* frames, const uint8_t* medians, const int32_t* pos,
+                         uint32_t n, uint8_t* masks, uint32_t* ncontours, uint16_t* canvas);
+int rmx_fdf_status(rmx_ctx* ctx);
+
 /* ---- nic: the frame codec on the collect loop --------------------------------------------- */
 
 /* nic::compress (nic.hpp:8-101; main.cpp:113-118 plugs it into frc::collector::collect as
@@ -238,7 +257,7 @@ void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
  * synchronisation while recording).  rmx_set_timing(ctx, 1) opens a measurement window (and
  * drops earlier samples); rmx_last_kernel_ms synchronises the stream and returns the AVERAGE
  * duration in milliseconds of `kernel` ("kpe_main", "kpe_finish", "kpe_table", "kpm_build", "kpm_match",
- * "fgm_blit", "nic_compress") over the launches of the window (0 if none).  An event pair
+ * "fgm_blit", "nic_compress", "fdf") over the launches of the window (0 if none).  An event pair
  * costs ~10 us of stream time per launch on this hardware: enabled = 2 records only
  * "kpe_main" (what bench.py uses inside its timed region), 0 switches recording off. */
 int rmx_set_timing(rmx_ctx* ctx, int enabled);

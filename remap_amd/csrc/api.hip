@@ -18,6 +18,7 @@
 #include "kpm_cell.hip"
 #include "fgm.hip"
 #include "nic.hip"
+#include "fdf.hip"
 
 using namespace rmx;
 
@@ -42,6 +43,8 @@ struct rmx_ctx {
   bool status_cached = false;
   KpmWorkspace kpm{};
   uint32_t* blit_ws = nullptr;  // fgm_blit binning workspace
+  void* fdf_ws = nullptr;       // foreground-filter labelling workspace for fdf_cap frames
+  uint32_t fdf_cap = 0;
   size_t blit_ws_bytes = 0;
   size_t ws_bytes = 0;
   // timing: HIP event pairs recorded on the context stream around each kernel launch,
@@ -51,7 +54,7 @@ struct rmx_ctx {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
   };
-  Track ms_kpe, ms_finish, ms_table, ms_kpm_build, ms_kpm_match, ms_blit, ms_nic;
+  Track ms_kpe, ms_finish, ms_table, ms_kpm_build, ms_kpm_match, ms_blit, ms_nic, ms_fdf;
   std::string err;
 };
 
@@ -194,9 +197,10 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->status) (void)hipFree(ctx->status);
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
+  if (ctx->fdf_ws) (void)hipFree(ctx->fdf_ws);
   if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic}) free_track(*t);
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) free_track(*t);
   delete ctx;
   return RMX_OK;
 }
@@ -215,7 +219,7 @@ int rmx_set_timing(rmx_ctx* ctx, int enabled) {
   ctx->timing = enabled == 2 ? 2 : (enabled != 0);
   // (re)start a measurement window: forget the pairs recorded so far
   RMX_HIP(hipStreamSynchronize(ctx->stream));
-  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic}) t->used = 0;
+  for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) t->used = 0;
   return RMX_OK;
 }
 
@@ -245,6 +249,8 @@ static int kernel_stats(rmx_ctx* ctx, const char* kernel, float* ms, uint32_t* l
     t = &ctx->ms_blit;
   else if (k == "nic_compress")
     t = &ctx->ms_nic;
+  else if (k == "fdf")
+    t = &ctx->ms_fdf;
   else
     return RMX_ERR_ARG;
   RMX_HIP(hipStreamSynchronize(ctx->stream));

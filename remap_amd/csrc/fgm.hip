@@ -95,6 +95,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
 // every canvas dot is read and written once.  Bins wrap modulo 2^16 exactly (fgm.hpp:14).
 struct BlitParams {
   const uint8_t* frames;
+  const uint8_t* mask;   // optional, same layout as frames: pixels with a non-zero byte are not counted (fgm.hpp:71-86)
   const int32_t* pos;
   const uint32_t* frag_id;
   uint32_t* canvas;  // canvas_h x canvas_w x 8 dwords
@@ -211,14 +212,23 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return 0xffffffffu;
       const uint8_t* srow = p.frames + ((size_t)g * H + (size_t)fy) * W;
       uint32_t w;
+      const uint8_t* mrow = p.mask ? p.mask + ((size_t)g * H + (size_t)fy) * W : nullptr;
       if (fx >= 0 && fx + 3 < W) {
         __builtin_memcpy(&w, srow + fx, 4);  // unaligned dword
-        return w & 0x0f0f0f0fu;
+        w &= 0x0f0f0f0fu;
+        if (mrow) {
+          uint32_t mw;
+          __builtin_memcpy(&mw, mrow + fx, 4);
+          const uint32_t nz = (((mw & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw) & 0x80808080u;  // bit 7 of every non-zero byte
+          w |= (nz >> 7) * 0xffu;                                                        // masked pixel -> "outside"
+        }
+        return w;
       }
       w = 0xffffffffu;
 #pragma unroll
       for (int j = 0; j < 4; ++j)
-        if (fx + j >= 0 && fx + j < W) w = (w & ~(0xffu << (8 * j))) | ((uint32_t)(srow[fx + j] & 0xfu) << (8 * j));
+        if (fx + j >= 0 && fx + j < W && !(mrow && mrow[fx + j]))
+          w = (w & ~(0xffu << (8 * j))) | ((uint32_t)(srow[fx + j] & 0xfu) << (8 * j));
       return w;
     };
     auto apply = [&](uint32_t w) {

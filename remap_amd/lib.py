@@ -32,7 +32,7 @@ SYMBOLS = [
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
-    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch",
+    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
 ]
 
 
@@ -111,6 +111,8 @@ def load():
     lib.rmx_nic_bound.restype = u32
     lib.rmx_nic_pack.argtypes = [vp, vp, u32, vp, vp, u32, vp]
     lib.rmx_nic_status.argtypes = [vp]
+    lib.rmx_fdf_filter_batch.argtypes = [vp, vp, u32, u32, vp, vp, vp, u32, vp, vp, vp]
+    lib.rmx_fdf_status.argtypes = [vp]
     lib.rmx_nic_decompress_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp]
     sz = C.c_size_t
     lib.rmx_malloc.argtypes = [vp, sz, C.POINTER(vp)]
@@ -269,6 +271,28 @@ class Context:
         self._chk(self.lib.rmx_frc_scan(self.h, dxdy.data_ptr(), matched.data_ptr(), n, int(first_is_start), cp,
                                         C.byref(cf), pos.data_ptr(), frag.data_ptr()), "rmx_frc_scan")
         return pos, frag, ((cp[0], cp[1]), cf.value)
+
+    # ---- fdf -------------------------------------------------------------------------------
+    def fdf_filter(self, bg, frames, medians, pos, canvas=None, check=True):
+        """fdf::filter for the frames of one fragment.  bg: (bh, bw) uint8 CUDA tensor (blend of
+        the fragment); frames/medians: (n, H, W) uint8; pos: (n, 2) int32 positions inside the
+        background; canvas: optional (bh, bw, 16) int16 tensor receiving the masked blit.
+        Returns (masks (n, H, W) uint8, ncontours (n,) int32) device tensors."""
+        t = self.torch
+        n = frames.shape[0]
+        assert bg.is_contiguous() and frames.is_contiguous() and medians.is_contiguous() and pos.is_contiguous()
+        assert pos.dtype == t.int32 and tuple(frames.shape[1:]) == (self.H, self.W)
+        masks = t.empty_like(frames)
+        ncont = t.empty(n, dtype=t.int32, device=self.device)
+        if canvas is not None:
+            assert tuple(canvas.shape) == (bg.shape[0], bg.shape[1], 16) and canvas.is_contiguous()
+        self._chk(self.lib.rmx_fdf_filter_batch(self.h, bg.data_ptr(), bg.shape[1], bg.shape[0], frames.data_ptr(),
+                                                medians.data_ptr(), pos.data_ptr(), n, masks.data_ptr(),
+                                                ncont.data_ptr(), canvas.data_ptr() if canvas is not None else None),
+                  "rmx_fdf_filter_batch")
+        if check:
+            self._chk(self.lib.rmx_fdf_status(self.h), "rmx_fdf_status")
+        return masks, ncont
 
     # ---- nic -------------------------------------------------------------------------------
     def nic_compress(self, images, pack=True):
