@@ -49,12 +49,21 @@ __device__ __forceinline__ bool fdf_interior(const FdfParams& p, uint32_t x, uin
   return x >= 1 && x + 1 < p.W && y >= 1 && y + 2 < p.H;
 }
 
+// Labels start as "leftmost pixel of my run of equal colour inside my wave" (a ballot, no
+// memory traffic), so the union-find only has to stitch runs: across wave boundaries and
+// between rows, once per pair of overlapping runs (fdf_merge).  A per-pixel union with the
+// left neighbour makes chains as long as the flat areas are wide: 7.5 ms vs 0.86 ms per 800 frames.
 __global__ __launch_bounds__(256) void fdf_init(FdfParams p) {
   const uint32_t P = p.W * p.H;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (size_t)p.n * P) return;
-  const uint32_t i = (uint32_t)(g % P), x = i % p.W, y = i / p.W;
-  p.label[g] = fdf_interior(p, x, y) ? i : FDF_NONE;
+  const bool live = g < (size_t)p.n * P;
+  const uint32_t i = live ? (uint32_t)(g % P) : 0, x = i % p.W, y = i / p.W, lane = threadIdx.x & 63u;
+  const bool in = live && fdf_interior(p, x, y);
+  const bool left_same = in && x >= 2 && p.median[g - 1] == p.median[g];
+  const uint64_t heads = __builtin_amdgcn_ballot_w64(!left_same || lane == 0);
+  if (!live) return;
+  const uint32_t start = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));  // last head at or before me
+  p.label[g] = in ? i - (lane - start) : FDF_NONE;
   p.area[g] = 0;
   p.minx[g] = FDF_NONE;
   p.maxx[g] = 0;
@@ -97,8 +106,25 @@ __global__ __launch_bounds__(256) void fdf_merge(FdfParams p) {
   const uint8_t* med = p.median + f0;
   uint32_t* L = p.label + f0;
   const uint8_t c = med[i];
-  if (x >= 2 && med[i - 1] == c) fdf_union(L, i, i - 1);
-  if (y >= 2 && med[i - p.W] == c) fdf_union(L, i, i - p.W);
+  const bool left_same = x >= 2 && med[i - 1] == c;
+  // a run that continues across a wave boundary
+  if (left_same && (threadIdx.x & 63u) == 0) fdf_union(L, i, i - 1);
+  // the run above: once per pair of overlapping runs — if my left neighbour continues my run
+  // and its upper neighbour continues the upper run, that pixel (or one further left) does it
+  if (y >= 2 && med[i - p.W] == c && !(left_same && med[i - p.W - 1] == c)) fdf_union(L, i, i - p.W);
+}
+
+// Lanes hold consecutive pixels.  True on the first lane of every run of lanes with the same
+// root in the same row; len = lanes in that run (inside this wave).  All lanes must call.
+__device__ __forceinline__ bool fdf_run_head(uint32_t root, uint32_t x, uint32_t& len) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t prev = (uint32_t)__shfl_up((int)root, 1);
+  const uint32_t px = (uint32_t)__shfl_up((int)x, 1);
+  const bool head = root != FDF_NONE && (lane == 0 || prev != root || px + 1 != x);
+  const uint64_t breaks = __builtin_amdgcn_ballot_w64(root == FDF_NONE || head);
+  const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
+  len = later ? (uint32_t)__builtin_ctzll(later) + 1 : 64 - lane;
+  return head;
 }
 
 __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
@@ -114,46 +140,38 @@ __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
     const int32_t bx = p.pos[2 * (g / P)], by = p.pos[2 * (g / P) + 1];
     if (p.frames[g] != p.bg[(size_t)(by + (int32_t)y) * p.bw + (size_t)(bx + (int32_t)x)]) p.seeded[f0 + root] = 1;
   }
-  // runs of equal roots along a row inside the wave: the run's first lane adds for all
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t prev = (uint32_t)__shfl_up((int)root, 1);
-  const uint32_t px = (uint32_t)__shfl_up((int)x, 1);
-  const bool head = root != FDF_NONE && (lane == 0 || prev != root || px + 1 != x);
-  const bool brk = root == FDF_NONE || head;  // a run ends before every lane that is not its continuation
-  const uint64_t breaks = __builtin_amdgcn_ballot_w64(brk);
-  if (head) {
-    const uint64_t later = lane == 63 ? 0ull : (breaks >> (lane + 1));
-    const uint32_t len = later ? (uint32_t)__builtin_ctzll(later) + 1 : 64 - lane;
-    atomicAdd(&p.area[f0 + root], len);
-    atomicMin(&p.minx[f0 + root], x);
-    atomicMax(&p.maxx[f0 + root], x + len - 1);
-    atomicMin(&p.miny[f0 + root], y);
-    atomicMax(&p.maxy[f0 + root], y);
-  }
+  // runs of equal roots along a row inside the wave: the run's first lane adds for all.  Only
+  // the area here — a frame's big background component takes thousands of these per frame on
+  // one address; its bounding box is never needed (fdf_keep adds boxes of kept components only)
+  uint32_t len;
+  if (fdf_run_head(root, x, len)) atomicAdd(&p.area[f0 + root], len);
 }
 
 __global__ __launch_bounds__(256) void fdf_keep(FdfParams p) {
   const uint32_t P = p.W * p.H;
   const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (size_t)p.n * P) return;
-  const uint32_t i = (uint32_t)(g % P);
+  const bool live = g < (size_t)p.n * P;
+  const uint32_t i = live ? (uint32_t)(g % P) : 0, x = i % p.W, y = i / p.W;
   const size_t f0 = g - i;
-  const uint32_t root = p.label[g];
+  const uint32_t root = live ? p.label[g] : FDF_NONE;
   const uint32_t limit = P / 5;  // fde.hpp:109-116
-  uint8_t m = 0;
-  if (root != FDF_NONE) {
-    const bool keep = p.seeded[f0 + root] && p.area[f0 + root] <= limit;
-    m = keep ? 1 : 0;
-    if (keep && root == i) {
-      uint32_t* list = p.kept + (size_t)(g / P) * (p.kept_cap + 1);
-      const uint32_t at = atomicAdd(&list[0], 1u);
-      if (at < p.kept_cap)
-        list[1 + at] = i;
-      else
-        atomicOr(&p.status[3], 1u);
-    }
+  const bool keep = root != FDF_NONE && p.seeded[f0 + root] && p.area[f0 + root] <= limit;
+  if (keep && root == i) {
+    uint32_t* list = p.kept + (size_t)(g / P) * (p.kept_cap + 1);
+    const uint32_t at = atomicAdd(&list[0], 1u);
+    if (at < p.kept_cap)
+      list[1 + at] = i;
+    else
+      atomicOr(&p.status[3], 1u);
   }
-  p.mask[g] = m;
+  uint32_t len;
+  if (fdf_run_head(keep ? root : FDF_NONE, x, len)) {  // bounding boxes of the kept components only
+    atomicMin(&p.minx[f0 + root], x);
+    atomicMax(&p.maxx[f0 + root], x + len - 1);
+    atomicMin(&p.miny[f0 + root], y);
+    atomicMax(&p.maxy[f0 + root], y);
+  }
+  if (live) p.mask[g] = keep ? 1 : 0;
 }
 
 // one workgroup per frame, its four waves take the kept components in turn
