@@ -272,6 +272,11 @@ template <typename C, typename Alloc>
 concept compressor = requires(C c) {
   { c(std::declval<sid::nat::aimg_t<Alloc>>()) } -> std::same_as<compressed_t>;
 };
+// what fdf::filter needs from the codec (icd.hpp:21-27)
+template <typename C, typename Alloc>
+concept decompressor = requires(C c) {
+  { c(std::declval<compressed_t>(), std::declval<mrl::dimensions_t>()) } -> std::same_as<sid::nat::aimg_t<Alloc>>;
+};
 }  // namespace icd
 
 namespace all {

@@ -122,6 +122,18 @@ public:
 
   // device view for callers that stay on the GPU (frc::collector, fgs)
   std::uint16_t* device_canvas() const noexcept { return canvas_.get<std::uint16_t>(); }
+  // for device-side batch blits (fdf::filter): the canvas, allocated and zeroed if it is not
+  // there yet, and the bookkeeping half of fragment::blit(pos, image, mask, no) (fgm.hpp:85)
+  std::uint16_t* device_canvas_ensure() {
+    if (!canvas_) {
+      rmx_ctx* c = any_ctx();
+      canvas_ = remap::device_buffer{c, dim_.area() * sizeof(dot_type)};
+      remap::check(rmx_memset(c, canvas_.get(), 0, dim_.area() * sizeof(dot_type)), c, "rmx_memset");
+      remap::check(rmx_sync(c), c, "rmx_sync");
+    }
+    return canvas_.get<std::uint16_t>();
+  }
+  void add_frame(std::size_t frame_no, point_t pos) { frames_.emplace_back(fgm::frame{frame_no, pos, {}}); }
 
 private:
   friend class frc::collector;

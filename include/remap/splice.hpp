@@ -1,8 +1,8 @@
 // remap/splice.hpp — namespaces fgs and mpb of the reference on top of the C ABI.
 //
 //   fgs::splice(first, last)                     (fgs.hpp:187-213)
-//   mpb::builder<Adapter>::collect / splice      (mpb.hpp:52-68; the stages around them —
-//                                                  aws, fdf, arf — are outside this path)
+//   mpb::builder<Adapter>::collect / splice / filter  (mpb.hpp:52-77; aws before and arf
+//                                                  after them are outside this path)
 //
 // Pixels and keypoints stay on the device: a snippet is a fragment (canvas in HBM) plus its
 // blend mask and single-region descriptor table, both device buffers produced by
@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "collector.hpp"
+#include "fdf.hpp"
 
 namespace fgs {
 
@@ -178,6 +179,13 @@ public:
   auto splice(std::list<fgm::fragment>& fragments) {
     auto result = fgs::splice(fragments.begin(), fragments.end());
     cb()(std::string{"spl"}, result);
+    return result;
+  }
+
+  // mpb.hpp:70-77 (needs the adapter's callbacks to accept the fdf per-frame call, main.cpp:150-163)
+  auto filter(mrl::dimensions_t const& window, std::vector<fgm::fragment>& fragments) {
+    auto result = fdf::filter(fragments, window, adapter_.get_compression(), cb());
+    cb()(std::string{"fdf"}, result);
     return result;
   }
 

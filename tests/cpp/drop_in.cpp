@@ -9,6 +9,7 @@
 #include <string>
 
 #include "frc.hpp"
+#include "fdf.hpp"
 #include "ful.hpp"
 #include "nic.hpp"
 #include "mpb.hpp"
@@ -129,6 +130,33 @@ static int run_nic(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob)
   return 0;
 }
 
+// collect (nic codec) -> fdf::filter (fdf.hpp:40-89): per frame kept contours and mask pixels,
+// per filtered fragment dims and canvas checksum
+static int run_fdf(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob) {
+  frc::collector collector{dim};
+  auto cb0 = [](fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) {};
+  collector.collect(mem_feed{dim, blob}, nic::compression{}, cb0);
+  auto list = collector.complete();
+  std::vector<fgm::fragment> fragments;
+  for (auto& f : list) fragments.push_back(std::move(f));
+  auto cb = [&](fgm::fragment const&, std::size_t idx, sid::nat::dimg_t const&, std::size_t no, sid::nat::dimg_t const&,
+                fgm::point_t const&, fdf::contours_t const& foreground, sid::mon::dimg_t const& mask) {
+    std::size_t px = 0;
+    unsigned long long h = 0;
+    for (auto const* m = mask.data(); m < mask.end(); ++m) {
+      px += m->value != 0;
+      h = h * 1000003ull + (m->value != 0);
+    }
+    std::printf("frame %zu frag %zu contours %zu maskpx %zu maskhash %llu\n", no, idx, foreground.size(), px, h);
+  };
+  auto out = fdf::filter(fragments, dim, nic::compression{}, cb);
+  std::size_t fi = 0;
+  for (auto& f : out)
+    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu\n", fi++, f.dimensions().width_,
+                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), canvas_sum(f));
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -146,6 +174,7 @@ int main(int argc, char** argv) {
   mrl::dimensions_t dim{W, H};
   if (argc > 4 && std::string(argv[4]) == "splice") return run_splice(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "nic") return run_nic(dim, blob);
+  if (argc > 4 && std::string(argv[4]) == "fdf") return run_fdf(dim, blob);
 
   frc::collector collector{dim};
   std::size_t calls = 0, entries = 0, last_no = 0;

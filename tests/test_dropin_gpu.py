@@ -155,3 +155,34 @@ def test_collect_with_nic_compression_blobs_match_oracle(gpu, tmp_path):
         assert blobs[i][0] == O.orc_nic_compress(f).hex(), i
         assert blobs[i][1] == O.orc_nic_compress(med).hex(), i
     assert lines[-1].startswith("single 1 ")
+
+
+def test_fdf_filter_drop_in_matches_reference(gpu, tmp_path):
+    """collect (nic::compression) -> fdf::filter through the drop-in headers: per-frame kept
+    contours and masks, filtered fragments == the reference's golden fdf::filter result."""
+    from test_oracle_golden import fdf_streams
+
+    exe = build_driver(str(tmp_path))
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fdf_cases.npz"))
+    for k, fr in enumerate(fdf_streams()):
+        n, H, W = fr.shape
+        blob = tmp_path / f"fdf{k}.bin"
+        fr.tofile(blob)
+        out = subprocess.run([exe, str(blob), str(W), str(H), "fdf"], check=True, capture_output=True, text=True).stdout
+        lines = [l.split() for l in out.strip().splitlines()]
+        frames = {int(l[1]): l for l in lines if l[0] == "frame"}
+        frags = [l for l in lines if l[0] == "fragment"]
+        want = np.unpackbits(g[f"masks{k}"])[: n * H * W].reshape(n, H, W)
+        assert sorted(frames) == list(range(n))
+        for i in range(n):
+            l = frames[i]
+            assert int(l[3]) == int(g[f"frag{k}"][i]) and int(l[5]) == int(g[f"ncontours{k}"][i]), (k, i)
+            assert int(l[7]) == int(want[i].sum()), (k, i)
+            h = 0
+            for v in want[i].reshape(-1):
+                h = (h * 1000003 + int(v)) & 0xFFFFFFFFFFFFFFFF
+            assert int(l[9]) == h, (k, i)
+        assert len(frags) == len(g[f"dims{k}"])
+        for f, l in enumerate(frags):
+            assert [int(l[3]), int(l[4])] == g[f"dims{k}"][f].tolist()
+            assert int(l[11]) == int(g[f"canvas_sum{k}"][f]), (k, f)
