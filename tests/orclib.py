@@ -390,12 +390,12 @@ def ref_ful_read(directory):
 
 
 def ref_fdf_lib():
-    if "f" not in _ref:
+    if "fdf" not in _ref:
         lib = _load_ref("libref_fdf.so")
         if lib is not None:
             lib.ref_fdf.restype = C.c_uint32
-        _ref["f"] = lib
-    return _ref["f"]
+        _ref["fdf"] = lib
+    return _ref["fdf"]
 
 
 def ref_fdf(frames, want=0):

@@ -103,3 +103,37 @@ def test_reference_reads_our_fragment_files(tmp_path):
     O.ref_ful_write(out, back)
     for k in range(3):
         assert (out / str(k)).read_bytes() == (tmp_path / str(k)).read_bytes()
+
+
+def test_nic_random_images_equal_reference():
+    rng = np.random.default_rng(31)
+    for k in range(300):
+        h, w = int(rng.integers(1, 40)), int(rng.integers(1, 60))
+        p = rng.random() ** 2
+        img = np.zeros(h * w, np.uint8)
+        v = int(rng.integers(0, 16))
+        for i in range(h * w):
+            if rng.random() < p:
+                v = int(rng.integers(0, 16))
+            img[i] = v
+        img = img.reshape(h, w)
+        pk = O.orc_nic_compress(img)
+        assert pk == O.ref_nic_compress(img), k
+        assert np.array_equal(O.ref_nic_decompress(pk, w, h), img)
+    # beyond the reference's uint16 domain its decoder still reads our split tokens
+    blank = np.full((240, 320), 6, np.uint8)
+    assert np.array_equal(O.ref_nic_decompress(O.orc_nic_compress(blank), 320, 240), blank)
+
+
+@pytest.mark.skipif(O.ref_fdf_lib() is None, reason="libref_fdf.so not built (needs AVX-512VL/BW)")
+def test_fdf_random_streams_equal_reference():
+    from remap_amd.synth import with_sprites
+
+    for seed, (n, w, h, dens) in enumerate([(14, 128, 64, 25), (10, 160, 96, 80), (12, 224, 64, 12), (8, 320, 128, 150)]):
+        fr, _ = scroller_v1(n, width=w, height=h, dens=dens)
+        fr = with_sprites(fr, n_sprites=2 + seed % 3, size=7 + 2 * seed, seed=40 + seed)
+        r, o = O.ref_fdf(fr), O.orc_fdf_filter(fr)
+        assert r["nfrag"] == o["nfrag"] and np.array_equal(r["frag"], o["frag"])
+        assert np.array_equal(r["masks"] != 0, o["masks"] != 0), seed
+        assert np.array_equal(r["ncontours"], o["ncontours"]), seed
+        assert np.array_equal(r["dots"], o["canvases"][0]), seed
