@@ -113,12 +113,35 @@ constexpr int BL_TW = 128, BL_TH = 8;
 
 // A frame overlaps at most W/128 + 2 tile columns; three tiny passes bin the batch's frames
 // by tile column so that a tile walks ~(W + 128) / (mean step) frames instead of all n.
+// counter[t] += 1 for every active lane, one atomic per distinct t in the wave (neighbouring
+// frames fall into the same few columns); returns the lane's own slot (old value + rank).
+__device__ __forceinline__ uint32_t wave_claim(uint32_t* counter, int t, bool active) {
+  const uint32_t lane = threadIdx.x & 63u;
+  uint32_t mine = 0;
+  uint64_t todo = __builtin_amdgcn_ballot_w64(active);
+  while (todo) {
+    const int leader = (int)__builtin_ctzll(todo);
+    const int tt = __shfl(t, leader);
+    const uint64_t same = __builtin_amdgcn_ballot_w64(active && t == tt);
+    uint32_t old = 0;
+    if ((int)lane == leader) old = atomicAdd(&counter[tt], (uint32_t)__builtin_popcountll(same));
+    old = (uint32_t)__shfl((int)old, leader);
+    if (active && t == tt) mine = old + (uint32_t)__builtin_popcountll(same & ((1ull << lane) - 1ull));
+    todo &= ~same;
+  }
+  return mine;
+}
+
 __global__ __launch_bounds__(256) void blit_bin_count(BlitParams p) {
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= p.n || (p.frag_id && p.frag_id[f] != p.fragment)) return;
-  const int ax = p.pos[2 * f] - p.zx;
-  const int t0 = max(ax, 0) / BL_TW, t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
-  for (int t = t0; t <= t1; ++t) atomicAdd(&p.col_cnt[t], 1u);
+  const bool live = f < p.n && !(p.frag_id && p.frag_id[f] != p.fragment);
+  int t0 = 0, t1 = -1;
+  if (live) {
+    const int ax = p.pos[2 * f] - p.zx;
+    t0 = max(ax, 0) / BL_TW;
+    t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+  }
+  for (int k = 0; __builtin_amdgcn_ballot_w64(t0 + k <= t1) != 0; ++k) wave_claim(p.col_cnt, t0 + k, t0 + k <= t1);
 }
 __global__ __launch_bounds__(1024) void blit_bin_scan(BlitParams p) {
   __shared__ uint32_t part[1024];
@@ -148,10 +171,22 @@ __global__ __launch_bounds__(1024) void blit_bin_scan(BlitParams p) {
 }
 __global__ __launch_bounds__(256) void blit_bin_fill(BlitParams p) {
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
-  if (f >= p.n || (p.frag_id && p.frag_id[f] != p.fragment)) return;
-  const int ax = p.pos[2 * f] - p.zx;
-  const int t0 = max(ax, 0) / BL_TW, t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
-  for (int t = t0; t <= t1; ++t) p.col_list[atomicAdd(&p.col_cur[t], 1u)] = f;
+  const bool live = f < p.n && !(p.frag_id && p.frag_id[f] != p.fragment);
+  int t0 = 0, t1 = -1;
+  if (live) {
+    const int ax = p.pos[2 * f] - p.zx;
+    t0 = max(ax, 0) / BL_TW;
+    t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+  }
+  for (int k = 0; __builtin_amdgcn_ballot_w64(t0 + k <= t1) != 0; ++k) {
+    const bool act = t0 + k <= t1;
+    const uint32_t at = wave_claim(p.col_cur, t0 + k, act);
+    if (act) p.col_list[at] = f;
+  }
+}
+
+__device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
+  return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
 }
 
 __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
@@ -167,23 +202,15 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   const int row = (int)(tid >> 5), xq = (int)(tid & 31u) * 4;  // this thread: 4 pixels of one row
   const int X = tx0 + xq, Y = ty0 + row;                      // canvas coordinates
   const uint32_t slot0 = (uint32_t)row * BL_TW + (tid & 31u);
-  // start from the canvas content (the canvas may already hold earlier batches)
+  // The bins hold only THIS launch's increments (at most 65 535 frames per launch, so no half
+  // of a word can overflow into the other): a pixel is then one fire-and-forget ds_add_u32,
+  // no read-modify-write chain, and the canvas content is added once at the end with its
+  // uint16 wraparound (fgm.hpp:14).
   const bool in_canvas_row = Y < (int)p.ch;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool inside = in_canvas_row && X + j < (int)p.cw;
-    const uint4* src = reinterpret_cast<const uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
-    uint4 a = inside ? src[0] : make_uint4(0, 0, 0, 0), b = inside ? src[1] : make_uint4(0, 0, 0, 0);
-    const uint32_t sl = slot0 + (uint32_t)j * 32;
-    bins[0][sl] = a.x;
-    bins[1][sl] = a.y;
-    bins[2][sl] = a.z;
-    bins[3][sl] = a.w;
-    bins[4][sl] = b.x;
-    bins[5][sl] = b.y;
-    bins[6][sl] = b.z;
-    bins[7][sl] = b.w;
-  }
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bins[k][slot0 + (uint32_t)j * 32] = 0;
   const int W = (int)p.W, H = (int)p.H;
   const uint32_t tcol = blockIdx.x % p.tiles_x;
   const uint32_t lbeg = p.col_cnt[tcol], lend = p.col_cnt[tcol + 1];  // this tile column's frames
@@ -203,55 +230,62 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
     }
     __syncthreads();
     const uint32_t m = nlist;
-    // eight frames per trip: all loads are issued before the first LDS update, so the load
-    // latency is paid once per eight frames instead of once per frame
-    auto fetch = [&](uint32_t i) -> uint32_t {
-      if (i >= m) return 0xffffffffu;  // 0xff in every byte = "outside the frame"
+    // fetch() only ISSUES the loads of one frame's four pixels (and mask bytes): every use of
+    // the loaded dwords is in apply(), so the loads of a whole trip are in flight together.
+    // A dword that would straddle the frame's left/right edge is loaded from the clamped
+    // position and shifted into place afterwards (sh = -3..3); sh = 8: nothing to add.
+    auto fetch = [&](uint32_t i, uint32_t& raw, uint32_t& mraw, int& sh) {
+      raw = 0;
+      mraw = 0;
+      sh = 8;
+      if (i >= m) return;
       const uint32_t g = list[i];
       const int fx = X - list_ax[i], fy = Y - list_ay[i];
-      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return 0xffffffffu;
-      const uint8_t* srow = p.frames + ((size_t)g * H + (size_t)fy) * W;
-      uint32_t w;
-      const uint8_t* mrow = p.mask ? p.mask + ((size_t)g * H + (size_t)fy) * W : nullptr;
-      if (fx >= 0 && fx + 3 < W) {
-        __builtin_memcpy(&w, srow + fx, 4);  // unaligned dword
-        w &= 0x0f0f0f0fu;
-        if (mrow) {
-          uint32_t mw;
-          __builtin_memcpy(&mw, mrow + fx, 4);
-          const uint32_t nz = (((mw & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw) & 0x80808080u;  // bit 7 of every non-zero byte
-          w |= (nz >> 7) * 0xffu;                                                        // masked pixel -> "outside"
-        }
-        return w;
-      }
-      w = 0xffffffffu;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (fx + j >= 0 && fx + j < W && !(mrow && mrow[fx + j]))
-          w = (w & ~(0xffu << (8 * j))) | ((uint32_t)(srow[fx + j] & 0xfu) << (8 * j));
+      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return;
+      const int fxc = min(max(fx, 0), W - 4);
+      const size_t off = ((size_t)g * H + (size_t)fy) * W + (size_t)fxc;
+      __builtin_memcpy(&raw, p.frames + off, 4);  // unaligned dword
+      if (p.mask) __builtin_memcpy(&mraw, p.mask + off, 4);
+      sh = fx - fxc;
+    };
+    auto place = [](uint32_t w, int sh, uint32_t fill) {  // bytes of the clamped dword -> pixel order, `fill` elsewhere
+      if (sh < 0) return (w << (8 * -sh)) | (fill >> (32 + 8 * sh));
+      if (sh > 0) return (w >> (8 * sh)) | (fill << (32 - 8 * sh));
       return w;
     };
-    auto apply = [&](uint32_t w) {
+    auto apply = [&](uint32_t raw, uint32_t mraw, int sh) {
+      if (sh == 8) return;
+      uint32_t w = place(raw & 0x0f0f0f0fu, sh, 0xffffffffu);  // 0xff in a byte = "outside the frame"
+      if (p.mask) {
+        const uint32_t mw = place(mraw, sh, 0u);
+        const uint32_t nz = (((mw & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw) & 0x80808080u;  // bit 7 of every non-zero byte
+        w |= (nz >> 7) * 0xffu;                                                        // masked pixel -> "outside"
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const uint32_t v = (w >> (8 * j)) & 0xffu;
-        if (v == 0xffu) continue;
-        uint32_t* word = &bins[v >> 1][slot0 + (uint32_t)j * 32];
-        const uint32_t old = *word;
-        *word = (v & 1u) ? old + 0x10000u : ((old & 0xffff0000u) | ((old + 1u) & 0xffffu));
+        // branch-free: a pixel outside the frame (0xff) adds 0 to a bin of its own slot
+        const uint32_t inc = v == 0xffu ? 0u : ((v & 1u) ? 0x10000u : 1u);
+        __hip_atomic_fetch_add(&bins[(v >> 1) & 7u][slot0 + (uint32_t)j * 32], inc, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     };
+    // eight frames per trip, the next trip's loads issued before this trip's updates
+    uint32_t cur[8], curm[8], nxt[8], nxtm[8];
+    int csh[8], nsh[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fetch((uint32_t)k, cur[k], curm[k], csh[k]);
     for (uint32_t i = 0; i < m; i += 8) {
-      const uint32_t w0 = fetch(i), w1 = fetch(i + 1), w2 = fetch(i + 2), w3 = fetch(i + 3), w4 = fetch(i + 4),
-                     w5 = fetch(i + 5), w6 = fetch(i + 6), w7 = fetch(i + 7);
-      apply(w0);
-      apply(w1);
-      apply(w2);
-      apply(w3);
-      apply(w4);
-      apply(w5);
-      apply(w6);
-      apply(w7);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) fetch(i + 8 + (uint32_t)k, nxt[k], nxtm[k], nsh[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) apply(cur[k], curm[k], csh[k]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        cur[k] = nxt[k];
+        curm[k] = nxtm[k];
+        csh[k] = nsh[k];
+      }
     }
   }
 #pragma unroll
@@ -259,8 +293,11 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
     if (in_canvas_row && X + j < (int)p.cw) {
       const uint32_t sl = slot0 + (uint32_t)j * 32;
       uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
-      dst[0] = make_uint4(bins[0][sl], bins[1][sl], bins[2][sl], bins[3][sl]);
-      dst[1] = make_uint4(bins[4][sl], bins[5][sl], bins[6][sl], bins[7][sl]);
+      const uint4 a = dst[0], b = dst[1];
+      dst[0] = make_uint4(add_u16x2(a.x, bins[0][sl]), add_u16x2(a.y, bins[1][sl]), add_u16x2(a.z, bins[2][sl]),
+                          add_u16x2(a.w, bins[3][sl]));
+      dst[1] = make_uint4(add_u16x2(b.x, bins[4][sl]), add_u16x2(b.y, bins[5][sl]), add_u16x2(b.z, bins[6][sl]),
+                          add_u16x2(b.w, bins[7][sl]));
     }
   }
 }
@@ -272,10 +309,6 @@ struct MergeParams {
   uint32_t dw, dh, sw, sh;
   int32_t ox, oy;
 };
-
-__device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
-  return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
-}
 
 __global__ __launch_bounds__(256) void fgm_merge(MergeParams p) {
   // one thread per (source pixel, half dot): 4 dwords = 8 bins
