@@ -34,6 +34,9 @@ struct rmx_ctx {
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
+  uint32_t overlap_subs = 0;    // RMX_OVERLAP: finish of sub-batch i on a second stream beside main of i + 1
+  hipStream_t aux = nullptr;
+  std::vector<hipEvent_t> ev_main, ev_fin;
   uint32_t sub_mib = 1u << 20;  // sub-batch footprint (MiB); default: whole batch in one launch (measured best)
   uint32_t* status = nullptr;  // [0] kpe overflow, [1] kpm capacity, [2..] scratch
   // status words as read back by the last rmx_frc_scan (which synchronises anyway); valid
@@ -176,6 +179,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   ctx->kmax = kmax;
   ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
   if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
+  if (const char* e = getenv("RMX_OVERLAP")) ctx->overlap_subs = (uint32_t)std::max(0, atoi(e));
   if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
@@ -198,6 +202,9 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->status) (void)hipFree(ctx->status);
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->fdf_ws) (void)hipFree(ctx->fdf_ws);
+  for (auto e : ctx->ev_main) (void)hipEventDestroy(e);
+  for (auto e : ctx->ev_fin) (void)hipEventDestroy(e);
+  if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) free_track(*t);
@@ -326,7 +333,20 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   // one launch pair for the whole batch.
   const size_t per_frame = (size_t)ctx->W * ctx->H * 2 + (size_t)((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * 4;
   uint32_t sub = (uint32_t)std::max<size_t>(1, ((size_t)ctx->sub_mib << 20) / per_frame);
-  for (uint32_t f0 = 0; f0 < n; f0 += sub) {
+  const bool overlap = ctx->overlap_subs > 1 && n >= 256 * ctx->overlap_subs;
+  if (overlap) {
+    sub = (n + ctx->overlap_subs - 1) / ctx->overlap_subs;
+    if (!ctx->aux) RMX_HIP(hipStreamCreateWithFlags(&ctx->aux, hipStreamNonBlocking));
+    while (ctx->ev_main.size() < ctx->overlap_subs) {
+      hipEvent_t a, b;
+      RMX_HIP(hipEventCreateWithFlags(&a, hipEventDisableTiming));
+      RMX_HIP(hipEventCreateWithFlags(&b, hipEventDisableTiming));
+      ctx->ev_main.push_back(a);
+      ctx->ev_fin.push_back(b);
+    }
+  }
+  uint32_t sub_idx = 0;
+  for (uint32_t f0 = 0; f0 < n; f0 += sub, ++sub_idx) {
     const uint32_t m = std::min(sub, n - f0);
     KpeParams p{};
     p.frames = frames + (size_t)f0 * ctx->W * ctx->H;
@@ -357,13 +377,20 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
         hipLaunchKernelGGL(kpe_main<false>, grid, dim3(256), 0, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
-    {
+    const uint32_t cpf = (p.HB * p.Wd + FIN_WORDS - 1) / FIN_WORDS;
+    if (overlap) {
+      RMX_HIP(hipEventRecord(ctx->ev_main[sub_idx], ctx->stream));
+      RMX_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_main[sub_idx], 0));
+      hipLaunchKernelGGL(kpe_finish, dim3(m * cpf), dim3(256), 0, ctx->aux, p);
+      RMX_HIP(hipEventRecord(ctx->ev_fin[sub_idx], ctx->aux));
+    } else {
       Timer t(ctx, &ctx->ms_finish);
-      const uint32_t cpf = (p.HB * p.Wd + FIN_WORDS - 1) / FIN_WORDS;
       hipLaunchKernelGGL(kpe_finish, dim3(m * cpf), dim3(256), 0, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
   }
+  if (overlap)
+    for (uint32_t i = 0; i < sub_idx; ++i) RMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[i], 0));
   TableParams tp{};
   tp.raw = ctx->raw;
   tp.kcount = ctx->kraw;
