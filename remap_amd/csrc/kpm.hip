@@ -903,22 +903,36 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   umap_order_par<64, RC>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
-// The instances behind kpm_build_small are launched on a FIXED grid that strides over the
-// frames: on a stream where kpm_build_small builds everything they cost a few microseconds
-// instead of a launch of n mostly empty workgroups each.
+// The instances behind kpm_build_small are launched on a FIXED grid; a workgroup looks at the
+// tier words of all its frames side by side first and only walks them if one asks for this
+// instance: on a stream where kpm_build_small builds
+// everything these launches cost their launch overhead, not n mostly empty workgroups.
+template <typename F>
+__device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want, uint32_t nslots, F&& frame) {
+  // workgroup b owns frames b, b + G, b + 2G, ... (neighbouring frames cost alike: striding
+  // spreads them over the workgroups)
+  const uint32_t G = gridDim.x, b = blockIdx.x;
+  const uint32_t K = b < nslots ? (nslots - b + G - 1) / G : 0;
+  for (uint32_t base = 0; base < K; base += blockDim.x) {
+    const uint32_t k = base + threadIdx.x;
+    const bool mine = tier == nullptr || (k < K && tier[b + k * G] == want);
+    if (!__syncthreads_or(mine)) continue;
+    const uint32_t end = min(K, base + blockDim.x);
+    for (uint32_t kk = base; kk < end; ++kk) {
+      const uint32_t fslot = b + kk * G;
+      if (tier && tier[fslot] != want) continue;  // uniform
+      frame(fslot);
+      __syncthreads();  // LDS is reused by the next frame
+    }
+  }
+}
 template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
 __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large, uint32_t nslots) {
-  for (uint32_t fslot = blockIdx.x; fslot < nslots; fslot += gridDim.x) {
-    kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot);
-    __syncthreads();  // LDS is reused by the next frame
-  }
+  kpm_for_tier(needs_large, 3u, nslots, [&](uint32_t fslot) { kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot); });
 }
 template <uint32_t RC, uint32_t TIN>
 __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
-  for (uint32_t fslot = blockIdx.x; fslot < nslots; fslot += gridDim.x) {
-    kpm_build_medium_frame<RC, TIN>(p, tier, fslot);
-    __syncthreads();
-  }
+  kpm_for_tier(tier, TIN, nslots, [&](uint32_t fslot) { kpm_build_medium_frame<RC, TIN>(p, tier, fslot); });
 }
 
 // ---- matching --------------------------------------------------------------------------------------
