@@ -180,6 +180,50 @@ struct BlockBarrier {
   __device__ __forceinline__ void operator()() const { __syncthreads(); }
 };
 
+// one level of umap_order_par held by ONE wave in registers: element t in slot t >> 6 of lane
+// t & 63; the bucket index (a Barrett reduction of the 64-bit hash) is computed once
+template <uint32_t KPL, typename Bar>
+__device__ __forceinline__ void umap_level_regs(const uint64_t* h, int level, uint32_t mk, uint32_t nk, uint32_t n2,
+                                                const uint16_t* cur, uint16_t* nxt, uint32_t* bmin, Bar bar, uint32_t lane) {
+  uint32_t bkt[KPL];
+#pragma unroll
+  for (uint32_t sl = 0; sl < KPL; ++sl) {
+    const uint32_t t = sl * 64 + lane;
+    bkt[sl] = 0;
+    if (t < mk) {
+      const uint32_t e = t < nk ? cur[t] : t;
+      bkt[sl] = umap_bucket(h[e], level);
+      atomicMin(&bmin[bkt[sl]], t);
+    }
+  }
+  bar();
+  uint32_t key[KPL];
+#pragma unroll
+  for (uint32_t sl = 0; sl < KPL; ++sl) {
+    const uint32_t t = sl * 64 + lane;
+    key[sl] = t < mk ? (0xffffu - bmin[bkt[sl]]) << 16 | (0xffffu - t) : 0xffffffffu;
+  }
+  if constexpr (KPL == 1) {
+    for (uint32_t k = 2; k <= n2; k <<= 1)
+      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+        const uint32_t other = (uint32_t)__shfl_xor((int)key[0], (int)j);
+        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
+        key[0] = (lower == up) ? min(key[0], other) : max(key[0], other);
+      }
+  } else {
+    wave_sort<KPL>(key, n2, lane);
+  }
+#pragma unroll
+  for (uint32_t sl = 0; sl < KPL; ++sl) {
+    const uint32_t j = sl * 64 + lane;
+    if (j < mk) {
+      const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
+      nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
+    }
+  }
+  bar();
+}
+
 template <uint32_t NT, uint32_t NMAX = 0xffffffffu, typename Bar, typename OutT>
 __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* keys, uint16_t* seq_a, uint16_t* seq_b,
                                       uint32_t* bmin, Bar bar, OutT* order, uint32_t tid) {
@@ -190,96 +234,27 @@ __device__ inline void umap_order_par(const uint64_t* h, uint32_t n, uint32_t* k
     const uint32_t B = kUmapBuckets[level], mk = min(B, n);
     for (uint32_t b = tid; b < B; b += NT) bmin[b] = 0xffffffffu;
     bar();
+    uint32_t n2 = 1;
+    while (n2 < mk) n2 <<= 1;
+    if (NT == 64 && n2 <= (NMAX > 256 ? 512u : NMAX > 64 ? 256u : 64u)) {
+      if (n2 <= 64)
+        umap_level_regs<1>(h, level, mk, nk, n2, cur, nxt, bmin, bar, tid);
+      else if (NMAX > 64 && n2 <= 256)
+        umap_level_regs<4>(h, level, mk, nk, n2, cur, nxt, bmin, bar, tid);
+      else if (NMAX > 256)
+        umap_level_regs<8>(h, level, mk, nk, n2, cur, nxt, bmin, bar, tid);
+      uint16_t* sw = cur;
+      cur = nxt;
+      nxt = sw;
+      nk = mk;
+      if (mk == n) break;
+      continue;
+    }
     for (uint32_t t = tid; t < mk; t += NT) {
       const uint32_t e = t < nk ? cur[t] : t;
       atomicMin(&bmin[umap_bucket(h[e], level)], t);
     }
     bar();
-    uint32_t n2 = 1;
-    while (n2 < mk) n2 <<= 1;
-    if (NT == 64 && n2 <= 64) {
-      // one key per lane
-      uint32_t key = 0xffffffffu;
-      if (tid < mk) {
-        const uint32_t e = tid < nk ? cur[tid] : tid;
-        key = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - tid);
-      }
-      for (uint32_t k = 2; k <= n2; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-          const uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
-          const bool up = (tid & k) == 0, lower = (tid & j) == 0;
-          key = (lower == up) ? min(key, other) : max(key, other);
-        }
-      if (tid < mk) {
-        const uint32_t t = 0xffffu - (key & 0xffffu);
-        nxt[tid] = (uint16_t)(t < nk ? cur[t] : t);
-      }
-      bar();
-      uint16_t* sw = cur;
-      cur = nxt;
-      nxt = sw;
-      nk = mk;
-      if (mk == n) break;
-      continue;
-    }
-    if (NT == 64 && NMAX > 64 && n2 <= 256) {
-      // a wave holds the whole level: sort in registers (element t in key[t >> 6] of lane t & 63)
-      uint32_t key[4];
-#pragma unroll
-      for (uint32_t sl = 0; sl < 4; ++sl) {
-        const uint32_t t = sl * 64 + tid;
-        key[sl] = 0xffffffffu;
-        if (t < mk) {
-          const uint32_t e = t < nk ? cur[t] : t;
-          key[sl] = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
-        }
-      }
-      wave_sort<4>(key, n2, tid);
-#pragma unroll
-      for (uint32_t sl = 0; sl < 4; ++sl) {
-        const uint32_t j = sl * 64 + tid;
-        if (j < mk) {
-          const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
-          nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
-        }
-      }
-      bar();
-      uint16_t* sw = cur;
-      cur = nxt;
-      nxt = sw;
-      nk = mk;
-      if (mk == n) break;
-      continue;
-    }
-    if (NT == 64 && NMAX > 256 && n2 <= 512) {
-      // a wave holds the whole level: sort in registers (element t in key[t >> 6] of lane t & 63)
-      uint32_t key[8];
-#pragma unroll
-      for (uint32_t sl = 0; sl < 8; ++sl) {
-        const uint32_t t = sl * 64 + tid;
-        key[sl] = 0xffffffffu;
-        if (t < mk) {
-          const uint32_t e = t < nk ? cur[t] : t;
-          key[sl] = (0xffffu - bmin[umap_bucket(h[e], level)]) << 16 | (0xffffu - t);
-        }
-      }
-      wave_sort<8>(key, n2, tid);
-#pragma unroll
-      for (uint32_t sl = 0; sl < 8; ++sl) {
-        const uint32_t j = sl * 64 + tid;
-        if (j < mk) {
-          const uint32_t t = 0xffffu - (key[sl] & 0xffffu);
-          nxt[j] = (uint16_t)(t < nk ? cur[t] : t);
-        }
-      }
-      bar();
-      uint16_t* sw = cur;
-      cur = nxt;
-      nxt = sw;
-      nk = mk;
-      if (mk == n) break;
-      continue;
-    }
     for (uint32_t t = tid; t < n2; t += NT) {
       uint32_t key = 0xffffffffu;
       if (t < mk) {
