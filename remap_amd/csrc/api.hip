@@ -409,7 +409,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   tp.rank_words = 0;
   if (words * 4 <= 65536) {
     tp.rank_words = (uint32_t)words;
-    lds = std::max(lds, words * 4);
+    lds = std::max<size_t>(128 * sizeof(uint64_t), words * 4);  // the sort then only sees frames with <= 128 keypoints
   }
   {
     Timer t(ctx, &ctx->ms_table);
