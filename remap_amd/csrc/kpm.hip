@@ -950,7 +950,7 @@ __device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const 
   uint32_t nd = 0;
   for (uint32_t i = 0; i < HSLOTS; i += 64) {
     uint32_t s = i + lane;
-    bool occ = hk[s] != 0;
+    bool occ = s < HSLOTS && hk[s] != 0;
     uint64_t bal = __builtin_amdgcn_ballot_w64(occ);
     if (occ) skey[nd + mbcnt(bal)] = (uint64_t)hs[s] << 32 | s;
     nd += (uint32_t)__builtin_popcountll(bal);
@@ -1226,9 +1226,10 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
 // On the sparse stream a region holds ~10 codes and ~10 point pairs, so a wave per (pair,
 // region) idles 50+ lanes and the 8x larger grid is pure launch/latency cost.  Here the lanes
 // run over the concatenated code lists of the eight regions; every region has its own
-// 64-slot offset table.  A pair with more than PW_MG codes, or a region with more than
+// 32-slot offset table.  A pair with more than PW_MG codes, or a region with more than
 // PW_DMAX distinct offsets, is passed on to the per-(pair, region) instances via the work list.
-constexpr uint32_t PW_MG = 256, PW_SLOTS = 64, PW_DMAX = 32;
+constexpr uint32_t PW_MG = 128, PW_SLOTS = 32, PW_DMAX = 16;  // 6 KB of LDS: 26 waves per CU (12 KB: 13)
+constexpr uint32_t PW_SPL = PW_SLOTS / 8;                      // slots per lane in the selection step
 
 __device__ __forceinline__ void push_items(uint32_t* work, bool mine, uint32_t item, uint32_t lane) {
   const uint64_t bal = __builtin_amdgcn_ballot_w64(mine);
@@ -1244,7 +1245,7 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
   __shared__ uint32_t mg_p[PW_MG], mg_c[PW_MG], mg_n[PW_MG], mg_base[PW_MG + 1];
   __shared__ uint64_t skey[PW_SLOTS], hh[PW_SLOTS];
   __shared__ uint16_t seq_a[PW_SLOTS], seq_b[PW_SLOTS], pos_of[PW_SLOTS];
-  __shared__ uint32_t okeys[PW_SLOTS], bmin[64];
+  __shared__ uint32_t okeys[PW_SLOTS], bmin[32];  // (<= 16 distinct offsets: 13 or 29 buckets)
 
   const uint32_t lane = threadIdx.x, q = blockIdx.x;
   uint32_t* tick = p.tickets + (size_t)q * 48;
@@ -1367,7 +1368,7 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
     const int32_t dx = (int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu);
     const int32_t dy = (int32_t)(pp >> 16) - (int32_t)(cp >> 16);
     const uint32_t key = off_key(dx, dy), tb = r * PW_SLOTS;
-    uint32_t s = (key * 2654435761u) >> 26;
+    uint32_t s = (key * 2654435761u) >> 27;
     for (uint32_t probes = 0;; ++probes) {
       const uint32_t v = atomicCAS(&hk[tb + s], 0u, key);
       if (v == 0u || v == key) {
@@ -1390,7 +1391,8 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
   uint32_t D = 0;  // distinct offsets of region rr
 #pragma unroll
   for (int r = 0; r < 8; ++r) {
-    const uint32_t d = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(hk[r * PW_SLOTS + lane] != 0));
+    const uint32_t d =
+        (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < PW_SLOTS && hk[r * PW_SLOTS + lane] != 0));
     if (d > PW_DMAX) fail |= 1u << r;
     if (rr == (uint32_t)r) D = d;
   }
@@ -1405,8 +1407,8 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
   for (int rd = 0; rd < 4; ++rd) {
     uint64_t m = 0;
 #pragma unroll
-    for (uint32_t i = 0; i < 8; ++i) {
-      const uint32_t s = sub * 8 + i;
+    for (uint32_t i = 0; i < PW_SPL; ++i) {
+      const uint32_t s = sub * PW_SPL + i;
       if (hk[tb + s] != 0 && !((taken >> i) & 1u)) {
         const uint64_t cand = (uint64_t)hc[tb + s] << 32 | (uint64_t)(0xffffffffu - s);
         m = cand > m ? cand : m;
@@ -1420,7 +1422,7 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
     best[rd] = m;
     if (m != 0) {
       const uint32_t s = 0xffffffffu - (uint32_t)m;
-      if ((s >> 3) == sub) taken |= 1u << (s & 7u);
+      if (s / PW_SPL == sub) taken |= 1u << (s % PW_SPL);
     }
   }
   const uint32_t c1 = (uint32_t)(best[0] >> 32), c2 = (uint32_t)(best[1] >> 32), c3 = (uint32_t)(best[2] >> 32),
