@@ -38,6 +38,16 @@ __device__ __forceinline__ uint64_t fnv_code(const uint32_t c[4]) {
   }
   return h;
 }
+// its low 32 bits (all a slot index needs): the same recurrence in 32-bit arithmetic
+__device__ __forceinline__ uint32_t fnv_code_lo(const uint32_t c[4]) {
+  uint32_t h = 2166136261u;
+#pragma unroll
+  for (int i = 0; i < 13; ++i) {
+    h ^= (c[i >> 2] >> (8 * (i & 3))) & 0xffu;
+    h *= 16777619u;
+  }
+  return h;
+}
 // cdt::offset_hash, cdt.hpp:158-171 (int32 -> size_t sign-extends)
 __device__ __forceinline__ uint64_t fnv_offset(int32_t x, int32_t y) {
   uint64_t h = 2166136261ull;
@@ -470,7 +480,7 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
       uint32_t wgt = c[3] & 0xfu;
       if (wgt == 2) atomicAdd(&s_w2, 1u);
       if (wgt == 1) atomicAdd(&s_w1, 1u);
-      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      uint32_t s = fnv_code_lo(c) & mask;
       for (;;) {
         uint32_t v = atomicCAS(&htl[s], EMPTY, i);
         if (v == EMPTY) break;
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     __builtin_amdgcn_wave_barrier();
     if (lane < e) {
       load_code(desc + ent[r][lane], c);
-      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      uint32_t s = fnv_code_lo(c) & mask;
       for (;;) {
         uint32_t v = atomicCAS(&htl[r][s], EMPTY, lane);
         if (v == EMPTY) break;
@@ -772,7 +782,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
       const uint32_t wgt = c[3] & 0xfu;
       w2 += wgt == 2u;
       w1 += wgt == 1u;
-      uint32_t s = (uint32_t)fnv_code(c) & mask;
+      uint32_t s = fnv_code_lo(c) & mask;
       for (;;) {
         uint32_t v = atomicCAS(&htl[r][s], EMPTY, i);
         if (v == EMPTY) break;
@@ -1072,7 +1082,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
       uint32_t c[4];
       load_gcode(Cc, p.kmax, ch[H_GOFF] + gc, c);
       if (use_all || (c[3] & 0xfu) == 2u) {
-        uint32_t s = (uint32_t)fnv_code(c) & pmask;
+        uint32_t s = fnv_code_lo(c) & pmask;
         for (;;) {
           uint32_t v = p_ht[s];
           if (v == 0) break;
@@ -1307,7 +1317,7 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
       uint32_t c[4];
       load_gcode(Cc, p.kmax, goff_c + gc, c);
       if (use_all || (c[3] & 0xfu) == 2u) {
-        uint32_t s = (uint32_t)fnv_code(c) & pmask;
+        uint32_t s = fnv_code_lo(c) & pmask;
         for (;;) {
           const uint32_t v = p_ht[htoff + s];
           if (v == 0) break;

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
       gc = c_giter[base + lane];
       uint32_t c[4];
       load_code(cdesc + c_gfirst[gc], c);
-      uint32_t s = (uint32_t)fnv_code(c) & pmaskh;
+      uint32_t s = fnv_code_lo(c) & pmaskh;
       for (;;) {
         uint32_t v = p_ht[s];
         if (v == 0) break;
