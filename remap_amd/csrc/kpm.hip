@@ -1033,11 +1033,18 @@ __device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const 
 template <int TIER, uint32_t KM_HSLOTS, uint32_t KM_HSHIFT, uint32_t KM_MG, uint32_t KM_DMAX, uint32_t KM_BK>
 __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   __shared__ uint32_t hk[KM_HSLOTS], hc[KM_HSLOTS], hs[KM_HSLOTS];  // key, count, first pair index
-  __shared__ uint32_t mg_p[KM_MG], mg_c[KM_MG], mg_base[KM_MG + 1];
-  __shared__ uint64_t hh[KM_DMAX];
+  // the shared-code list (steps a, b) and the tie path's sort scratch (after b) share storage:
+  // LDS per wave decides how many (pair, region) items a CU has in flight
+  constexpr uint32_t MG_BYTES = (3 * KM_MG + 1) * 4, TIE_BYTES = (8 + 8 + 4) * KM_DMAX;
+  __shared__ __attribute__((aligned(8))) uint8_t shared_ab[MG_BYTES > TIE_BYTES ? MG_BYTES : TIE_BYTES];
+  uint32_t* const mg_p = reinterpret_cast<uint32_t*>(shared_ab);
+  uint32_t* const mg_c = mg_p + KM_MG;
+  uint32_t* const mg_base = mg_c + KM_MG;
+  uint64_t* const skey = reinterpret_cast<uint64_t*>(shared_ab);
+  uint64_t* const hh = skey + KM_DMAX;
+  uint32_t* const okeys = reinterpret_cast<uint32_t*>(hh + KM_DMAX);
   __shared__ uint16_t seq_a[KM_DMAX], seq_b[KM_DMAX], pos_of[KM_DMAX];
-  __shared__ uint32_t okeys[KM_DMAX], bmin[KM_BK];
-  __shared__ uint64_t skey[KM_DMAX];
+  __shared__ uint32_t bmin[KM_BK];
 
   const uint32_t lane = threadIdx.x;
   // TIER 0: one (pair, region) per workgroup.  Above: a fixed grid walks the work list the
