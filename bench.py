@@ -59,6 +59,22 @@ def cpu_baseline(frames_host):
                       f"{dt:.1f} s"}
 
 
+VALU_RATE_PER_NS = 558.0  # wave-instructions per ns, whole chip: v_min3/med3/max3_u32 streams, tools/micro/valu_rate.hip
+
+
+def pmc_valu(n_local, dens):
+    """VALU wave-instructions of one kpe_main launch from the same committed PMC passes."""
+    if n_local != FRAMES_PER_GPU or dens != DENS:
+        return None
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_main.json")))
+    try:
+        return float(json.load(open(files[-1]))["counters_mean_per_launch"]["SQ_INSTS_VALU"])
+    except Exception:
+        return None
+
+
 def pmc_traffic(n_local, dens):
     """HBM bytes per kpe_main launch from the committed rocprofv3 --pmc passes of this same
     workload (profiles/*_pmc_kpe_main.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py:
@@ -210,15 +226,20 @@ def main():
     barrier()
     dth = time.perf_counter() - t2
     # what a plain device copy of the same footprint reaches on this box (the practical HBM
-    # ceiling next to the 8 TB/s spec figure): read n*W*H + write n*W*H bytes
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    stage.copy_(frames)
-    ev0.record()
-    for _ in range(10):
-        stage.copy_(frames)
-    ev1.record()
-    torch.cuda.synchronize()
-    copy_gbs = 2.0 * frames.numel() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+    # ceiling next to the 8 TB/s spec figure): read n*W*H + write n*W*H bytes, with the library's
+    # own streaming copy kernel (rmx_copy) and, for reference, torch's device copy
+    def copy_rate(fn):
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fn()
+        ev0.record()
+        for _ in range(10):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return 2.0 * frames.numel() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+
+    copy_gbs = copy_rate(lambda: al.ctx.copy(stage, frames))
+    torch_copy_gbs = copy_rate(lambda: stage.copy_(frames))
     del pinned, stage
 
     tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
@@ -233,6 +254,10 @@ def main():
         alg_bytes = (2.0 * W * H * n_local + 18.0 * ktot) / max(1.0, launches_per_step)
         achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
         traffic = pmc_traffic(n_local, args.dens) if launches_per_step == 1 else None
+        valu = pmc_valu(n_local, args.dens) if launches_per_step == 1 else None
+        # what actually bounds kpe_main: ~52 integer VALU ops per 4 pixels against
+        # the chip's measured VALU issue rate; reported beside the contract's HBM figure
+        valu_floor_ms = valu / VALU_RATE_PER_NS * 1e-6 if valu else None
         line = {
             "metric": "aligned frames/s, 320x240 stream (kpe+kpm+frc), offsets bit-exact",
             "value": n_total * args.steps / dt,
@@ -259,6 +284,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "kpe_main",
                          "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
+                         "torch_device_copy_gbs": torch_copy_gbs,
+                         "valu_wave_instructions": valu, "valu_floor_ms": valu_floor_ms,
+                         "frac_of_valu_floor": (valu_floor_ms / ms_kpe) if valu_floor_ms and ms_kpe > 0 else None,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:

@@ -180,6 +180,11 @@ class Context:
     def sync(self):
         self._chk(self.lib.rmx_sync(self.h), "rmx_sync")
 
+    def copy(self, dst, src):
+        """rmx_copy: device-to-device copy of a contiguous tensor on the context stream."""
+        assert dst.is_contiguous() and src.is_contiguous() and dst.numel() * dst.element_size() == src.numel() * src.element_size()
+        self._chk(self.lib.rmx_copy(self.h, dst.data_ptr(), src.data_ptr(), src.numel() * src.element_size()), "rmx_copy")
+
     def set_timing(self, on=True):
         """True / 1: HIP event pairs around every kernel; 2: around kpe_main only; False: off."""
         self.lib.rmx_set_timing(self.h, int(on))
