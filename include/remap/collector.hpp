@@ -204,16 +204,21 @@ public:
     bool first = true;
     std::int32_t carry_pos[2] = {0, 0};
     std::uint32_t carry_frag = 0;
+    remap::detail::phase_clock clk;
     while (feed.has_more()) {
+      clk.mark(nullptr);
       // ---- drain one block of the feed into host arenas, stage it into HBM ----
       all::memory_pool pool;
       std::vector<frame_type> block;
       while (feed.has_more() && block.size() < block_frames) block.push_back(feed.produce(pixel_alloc_t{pool}));
       const std::uint32_t n = std::uint32_t(block.size());
+      clk.mark("feed.produce");
       reserve(n);
-      for (std::uint32_t i = 0; i < n; ++i)
-        remap::check(rmx_upload(ctx_, frames_.get<std::uint8_t>() + i * area, block[i].image_.data(), area), ctx_,
-                     "rmx_upload");
+      // frames are gathered in page-locked memory and cross PCIe in one copy
+      stage_.reserve(ctx_, std::size_t(n) * area);
+      for (std::uint32_t i = 0; i < n; ++i) std::memcpy(stage_.get<std::uint8_t>() + i * area, block[i].image_.data(), area);
+      remap::check(rmx_upload(ctx_, frames_.get<std::uint8_t>(), stage_.get(), std::size_t(n) * area), ctx_, "rmx_upload");
+      clk.mark("stage + upload");
       // ---- the hot path, all on the device ----
       remap::check(rmx_kpe_batch(ctx_, frames_.get<std::uint8_t>(), n, median_.get<std::uint8_t>(),
                                  desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>()),
@@ -235,20 +240,22 @@ public:
                    ctx_, "rmx_copy");
       remap::check(rmx_copy(ctx_, halo_.get<std::uint8_t>() + kmax * sizeof(rmx_desc), kcount_.get<std::uint32_t>() + (n - 1), 4),
                    ctx_, "rmx_copy");
+      clk.mark("device: kpe + kpm + scan");
       // ---- results to the host ----
       h_pos_.resize(2 * n);
       h_frag_.resize(n);
       h_k_.resize(n);
-      h_med_.resize(n * area);
+      h_med_.reserve(ctx_, std::size_t(n) * area);
       const std::uint32_t tstride = std::max<std::uint32_t>(1, std::min(maxk, kmax));  // rows actually used
       h_tab_.resize(std::size_t(n) * tstride);
       remap::check(rmx_download(ctx_, h_pos_.data(), pos_.get(), 8 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_frag_.data(), frag_.get(), 4 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_k_.data(), kcount_.get(), 4 * n), ctx_, "rmx_download");
-      remap::check(rmx_download(ctx_, h_med_.data(), median_.get(), n * area), ctx_, "rmx_download");
+      remap::check(rmx_download(ctx_, h_med_.get(), median_.get(), n * area), ctx_, "rmx_download");
       remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax * sizeof(rmx_desc),
                                    tstride * sizeof(rmx_desc), n),
                    ctx_, "rmx_download_2d");
+      clk.mark("downloads");
       // ---- frame blobs: nic::compression is run on the device for the whole block (two
       // launches: images, medians); any other compressor is called per frame below ----
       constexpr bool device_codec = std::is_same_v<std::decay_t<Comp>, nic::compression>;
@@ -257,6 +264,7 @@ public:
         pk_image = nic::detail::compress_device(ctx_, frames_.get<std::uint8_t>(), n, std::uint32_t(area));
         pk_median = nic::detail::compress_device(ctx_, median_.get<std::uint8_t>(), n, std::uint32_t(area));
       }
+      clk.mark("codec");
       // ---- device blit of the block, fragment by fragment (frc.hpp:129-135) ----
       for (std::uint32_t i = 0; i < n;) {
         std::uint32_t j = i;
@@ -272,7 +280,7 @@ public:
         // ---- replay: bookkeeping + callback per frame, in order (frc.hpp:117-119) ----
         for (std::uint32_t t = i; t < j; ++t) {
           image_type median{dim_, pixel_alloc_t{pool}};
-          std::memcpy(median.data(), h_med_.data() + t * area, area);
+          std::memcpy(median.data(), h_med_.get<std::uint8_t>() + t * area, area);
           fgm::point_t p{h_pos_[2 * t], h_pos_[2 * t + 1]};
           if constexpr (device_codec)
             current_->frames_.emplace_back(
@@ -288,6 +296,7 @@ public:
         i = j;
       }
       remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
+      clk.mark("blit + replay (grids, medians, callbacks)");
       first = false;
     }
   }
@@ -322,7 +331,9 @@ private:
   remap::device_buffer frames_, median_, desc_, kcount_, dxdy_, matched_, pos_, frag_, halo_;
   std::vector<std::int32_t> h_pos_;
   std::vector<std::uint32_t> h_frag_, h_k_;
-  std::vector<std::uint8_t> h_med_;
+  // page-locked staging (medians coming back, frames going in); shared by the collectors of
+  // a thread: allocating 300 MB of pinned memory costs tens of milliseconds
+  static inline thread_local remap::pinned_buffer h_med_, stage_;
   std::vector<rmx_desc> h_tab_;
   std::list<fgm::fragment> fragments_;
   fgm::fragment* current_{nullptr};

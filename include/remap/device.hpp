@@ -6,7 +6,10 @@
 // remap::device_error — there is no CPU fallback behind these headers.
 #pragma once
 
+#include <chrono>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -85,6 +88,56 @@ public:
   T* get() const noexcept { return static_cast<T*>(p_); }
   std::size_t bytes() const noexcept { return bytes_; }
   explicit operator bool() const noexcept { return p_ != nullptr; }
+
+private:
+  rmx_ctx* ctx_{nullptr};
+  void* p_{nullptr};
+  std::size_t bytes_{0};
+};
+
+namespace detail {
+// REMAP_PROFILE=1: wall time per phase of a host-side loop, printed to stderr at destruction.
+class phase_clock {
+public:
+  phase_clock() : on_{std::getenv("REMAP_PROFILE") != nullptr}, last_{std::chrono::steady_clock::now()} {}
+  void mark(char const* name) {
+    if (!on_) return;
+    const auto now = std::chrono::steady_clock::now();
+    if (name) acc_[name] += std::chrono::duration<double>(now - last_).count();
+    last_ = now;
+  }
+  ~phase_clock() {
+    if (!on_) return;
+    for (auto const& [k, v] : acc_) std::fprintf(stderr, "[remap] %-44s %8.1f ms\n", k.c_str(), v * 1e3);
+  }
+
+private:
+  bool on_;
+  std::chrono::steady_clock::time_point last_;
+  std::map<std::string, double> acc_;
+};
+}  // namespace detail
+
+// Page-locked host staging tied to a context (grow-only).
+class pinned_buffer {
+public:
+  pinned_buffer() = default;
+  pinned_buffer(pinned_buffer const&) = delete;
+  pinned_buffer& operator=(pinned_buffer const&) = delete;
+  ~pinned_buffer() {
+    if (p_) rmx_free_host(ctx_, p_);
+  }
+  void reserve(rmx_ctx* c, std::size_t bytes) {
+    if (bytes <= bytes_ && c == ctx_) return;
+    if (p_) rmx_free_host(ctx_, p_);
+    p_ = nullptr;
+    bytes_ = 0;
+    ctx_ = c;
+    check(rmx_malloc_host(c, bytes, &p_), c, "rmx_malloc_host");
+    bytes_ = bytes;
+  }
+  template <typename T = void>
+  T* get() const noexcept { return static_cast<T*>(p_); }
 
 private:
   rmx_ctx* ctx_{nullptr};

@@ -283,6 +283,17 @@ int rmx_malloc(rmx_ctx* ctx, size_t bytes, void** out) {
   RMX_HIP(hipMalloc(out, bytes));
   return RMX_OK;
 }
+int rmx_malloc_host(rmx_ctx* ctx, size_t bytes, void** out) {
+  if (!ctx || !out) return RMX_ERR_ARG;
+  RMX_HIP(hipSetDevice(ctx->device));
+  RMX_HIP(hipHostMalloc(out, bytes, hipHostMallocDefault));
+  return RMX_OK;
+}
+int rmx_free_host(rmx_ctx* ctx, void* ptr) {
+  if (!ctx) return RMX_ERR_ARG;
+  if (ptr) RMX_HIP(hipHostFree(ptr));
+  return RMX_OK;
+}
 int rmx_free(rmx_ctx* ctx, void* ptr) {
   if (!ctx) return RMX_ERR_ARG;
   RMX_HIP(hipSetDevice(ctx->device));

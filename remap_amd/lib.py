@@ -32,7 +32,7 @@ SYMBOLS = [
     "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
-    "rmx_memset", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
+    "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
 ]
 
 
@@ -117,6 +117,8 @@ def load():
     sz = C.c_size_t
     lib.rmx_malloc.argtypes = [vp, sz, C.POINTER(vp)]
     lib.rmx_free.argtypes = [vp, vp]
+    lib.rmx_malloc_host.argtypes = [vp, sz, C.POINTER(vp)]
+    lib.rmx_free_host.argtypes = [vp, vp]
     lib.rmx_upload.argtypes = [vp, vp, vp, sz]
     lib.rmx_download.argtypes = [vp, vp, vp, sz]
     lib.rmx_download_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]

@@ -3,6 +3,7 @@
 // against the device-backed drop-in headers.  Prints what tests/test_dropin_gpu.py checks.
 //
 //   g++ -std=c++20 -O1 -Iinclude -Iinclude/remap/compat tests/cpp/drop_in.cpp -Lremap_amd -lremap_amd ...
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <fstream>
@@ -157,6 +158,25 @@ static int run_fdf(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob)
   return 0;
 }
 
+// throughput of frc::collector::collect through the drop-in layer (host feed, callbacks and all)
+static int run_time(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob, bool codec) {
+  for (int rep = 0; rep < 2; ++rep) {  // the second pass has the context, workspace and pools warm
+    frc::collector collector{dim};
+    std::size_t calls = 0;
+    auto cb = [&](fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) { ++calls; };
+    const auto t0 = std::chrono::steady_clock::now();
+    if (codec)
+      collector.collect(mem_feed{dim, blob}, nic::compression{}, cb);
+    else
+      collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+    auto frags = collector.complete();
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    std::printf("collect pass %d: %zu frames, %zu fragments, %.3f s, %.0f frames/s (%s)\n", rep, calls + 1, frags.size(), dt,
+                double(calls + 1) / dt, codec ? "nic::compression" : "no-op codec");
+  }
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -175,6 +195,8 @@ int main(int argc, char** argv) {
   if (argc > 4 && std::string(argv[4]) == "splice") return run_splice(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "nic") return run_nic(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "fdf") return run_fdf(dim, blob);
+  if (argc > 4 && std::string(argv[4]) == "time") return run_time(dim, blob, false);
+  if (argc > 4 && std::string(argv[4]) == "timenic") return run_time(dim, blob, true);
 
   frc::collector collector{dim};
   std::size_t calls = 0, entries = 0, last_no = 0;
