@@ -138,3 +138,28 @@ def test_sharded_blit_sums_to_the_whole_canvas(gpu):
                 al.ctx.fgm_merge(acc, c, (z[0] - gz[0], z[1] - gz[1]))
         assert torch.equal(acc, canvas), fid
     al.close()
+
+
+def test_blit_more_than_65535_frames_in_one_call(gpu):
+    """A launch accumulates into 16-bit halves, so rmx_fgm_blit_batch cuts a batch of more than
+    65 535 frames into several launches; counts beyond 65 535 wrap like fgm::dot_type."""
+    import torch
+
+    n, H, W = 70000, 8, 16
+    rng = np.random.default_rng(4)
+    frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
+    frames[:, 0, 0] = 5  # one bin that sees every frame: 70 000 mod 65 536
+    pos = np.zeros((n, 2), np.int32)
+    pos[n // 2:, 0] = 3  # second half shifted: two overlapping placements
+    ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+    cw, ch, zx, zy = ctx.fgm_extent(pos)
+    canvas = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+    ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy))
+    got = canvas.cpu().numpy().view(np.uint16)
+    want = np.zeros((ch, cw, 16), np.uint64)
+    for half, x0 in ((frames[: n // 2], 0), (frames[n // 2:], 3)):
+        for c in range(16):
+            want[:H, x0 - zx:x0 - zx + W, c] += (half == c).sum(axis=0).astype(np.uint64)
+    assert np.array_equal(got, (want % 65536).astype(np.uint16))
+    assert int(got[0, 0, 5]) == (n // 2) % 65536 and int(want[0, 0, 5]) == n // 2
+    ctx.close()
