@@ -732,9 +732,12 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint3
 // 512: 139 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
 template <uint32_t RC, uint32_t TIN>
 __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, uint32_t* tier, uint32_t fslot) {
-  __shared__ uint16_t ent[8][RC], slot_of[8][RC], gid_of[8][RC], seq_a[8][RC], seq_b[8][RC];
-  __shared__ uint32_t htl[8][2 * RC], keys[8][RC], bmin[8][RC == 256 ? 257 : 541];
+  // (the map-order scratch lives in arrays that are dead by then: see the umap_order_par call;
+  // 53 KB instead of 70 for RC = 256 lets a CU hold three workgroups instead of two)
+  __shared__ uint16_t ent[8][RC], slot_of[8][RC], gid_of[8][RC];
+  __shared__ uint32_t htl[8][2 * RC], keys[8][RC];
   __shared__ uint64_t hg[8][RC];
+  static_assert(RC / 2 + (RC == 256 ? 257 : 541) <= 2 * RC, "seq_a + bmin must fit the region's hash table");
   __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big;
 
@@ -884,8 +887,11 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     h[H_W1] = w1;
   }
   wbar();
-  // keys[r] is free again: iteration order of this region's code map
-  umap_order_par<64, RC>(hg[r], G, keys[r], seq_a[r], seq_b[r], bmin[r], wbar, pool + kpm_off_giter(p.kmax) + g_off, lane);
+  // iteration order of this region's code map.  Scratch: keys[r] is free again; the region's
+  // hash table (exported above) now holds seq_a (RC u16) and the bucket minima behind it, and
+  // slot_of[r] (last read when the sort keys were formed) holds seq_b
+  umap_order_par<64, RC>(hg[r], G, keys[r], reinterpret_cast<uint16_t*>(htl[r]), slot_of[r], htl[r] + RC / 2, wbar,
+                         pool + kpm_off_giter(p.kmax) + g_off, lane);
 }
 
 // The instances behind kpm_build_small are launched on a FIXED grid; a workgroup looks at the
