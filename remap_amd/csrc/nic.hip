@@ -92,8 +92,10 @@ constexpr uint32_t NIC_T = 256;
 constexpr uint32_t NIC_CW = 19;                    // dwords per thread and segment (odd: thread t's
                                                    // k-th word sits in bank (19 t + k) mod 64, conflict-free)
 constexpr uint32_t NIC_SEG = NIC_T * NIC_CW * 4;   // pixels per segment (19 456; 19 KB of LDS)
-constexpr uint32_t NIC_OUT = 64 * NIC_CW * 3;      // bytes a wave's chunks can produce from tokens of their own
-                                                   // pixels (3/4 byte per pixel); staged in LDS, written coalesced
+constexpr uint32_t NIC_OUT = 1536;                 // bytes of a wave's tokens staged in LDS and written coalesced
+                                                   // (a wave-segment makes ~0.5-1.3 KB on the bench streams; 3.6 KB
+                                                   // at worst — then, or with tokens reaching far back, it writes
+                                                   // straight to global memory); 27 KB per workgroup: five per CU
 constexpr uint32_t NIC_WORDS = NIC_T * NIC_CW + 4; // + 4 pixels before, 12 after (stencil reach)
 
 // byte-wise flags (bit 7 of each byte) -> 4 bits
@@ -108,7 +110,7 @@ __device__ __forceinline__ uint32_t nic_nib(uint32_t x) { return ((x >> 7) | (x 
 // 19 dwords (no walk, no divergence) and a token's length is the distance to the previous
 // T bit — carried across chunks by a max-scan and across segments in LDS.  Sizes -> sum-scan
 // -> offsets -> emission, both loops running over the chunk's tokens, not its pixels.
-__global__ __launch_bounds__(NIC_T) void nic_compress(NicParams p) {
+__global__ __launch_bounds__(NIC_T, 6) void nic_compress(NicParams p) {
   __shared__ uint32_t s_px[NIC_WORDS];  // word w <-> pixels seg0 - 4 + 4 w ...
   __shared__ uint8_t s_out[4][NIC_OUT];
   __shared__ int32_t s_max[4];
