@@ -30,60 +30,91 @@ __device__ __forceinline__ ScanSeg seg_shfl_up(const ScanSeg& v, int o) {
   return ScanSeg{__shfl_up(v.r, o), __shfl_up(v.x, o), __shfl_up(v.y, o), __shfl_up(v.c, o)};
 }
 
+// One 1024-thread workgroup; the stream is taken in spans of 16 384 frames (16 per thread, held
+// in registers: every frame is loaded once, all loads of a thread in flight together) with the
+// carry handed from span to span.
+constexpr uint32_t SCAN_PER = 16;
+
 __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
   __shared__ ScanSeg s_wave[16];
+  __shared__ ScanSeg s_carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint32_t chunk = (p.n + 1023) / 1024;
-  const uint32_t i0 = min(p.n, tid * chunk), i1 = min(p.n, i0 + chunk);
-  int32_t reset = 0, dx = 0, dy = 0, cnt = 0;
-  for (uint32_t i = i0; i < i1; ++i) {
-    bool brk = (i == 0 && p.first_is_start) || !p.matched[i];
-    if (brk) {
-      reset = 1;
-      dx = dy = 0;
-      cnt += (i == 0 && p.first_is_start) ? 0 : 1;
-    } else {
-      dx += p.dxdy[2 * i];
-      dy += p.dxdy[2 * i + 1];
-    }
-  }
-  // segmented scan of the 1024 chunk summaries: wave-inclusive by shuffles, the 16 wave
-  // totals by one thread, seeded with the carry
-  ScanSeg inc{reset, dx, dy, cnt};
+  if (tid == 0) s_carry = ScanSeg{0, p.carry_in[0], p.carry_in[1], p.carry_in[2]};
+  for (uint32_t base = 0; base < p.n; base += 1024 * SCAN_PER) {
+    const uint32_t span = min(p.n - base, 1024u * SCAN_PER);
+    const uint32_t chunk = (span + 1023) / 1024;  // <= SCAN_PER
+    const uint32_t i0 = base + min(span, tid * chunk), i1 = base + min(span, tid * chunk + chunk);
+    int32_t ddx[SCAN_PER], ddy[SCAN_PER];
+    uint32_t brk = 0;  // bit k: frame i0 + k starts a fragment
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const ScanSeg t = seg_shfl_up(inc, o);
-    if (lane >= (uint32_t)o) inc = seg_join(t, inc);
+    for (uint32_t k = 0; k < SCAN_PER; ++k) {
+      const uint32_t i = i0 + k;
+      const bool in = i < i1;
+      const uint32_t ic = in ? i : (p.n - 1);
+      const uint8_t m = p.matched[ic];
+      ddx[k] = p.dxdy[2 * ic];
+      ddy[k] = p.dxdy[2 * ic + 1];
+      if (in && ((i == 0 && p.first_is_start) || !m)) brk |= 1u << k;
+    }
+    const uint32_t cntk = i1 - i0;
+    int32_t reset = 0, dx = 0, dy = 0, cnt = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; ++k)
+      if (k < cntk) {
+        if ((brk >> k) & 1u) {
+          reset = 1;
+          dx = dy = 0;
+          cnt += (i0 + k == 0 && p.first_is_start) ? 0 : 1;
+        } else {
+          dx += ddx[k];
+          dy += ddy[k];
+        }
+      }
+    // segmented scan of the 1024 chunk summaries: wave-inclusive by shuffles, the 16 wave
+    // totals by one thread, seeded with the carry
+    ScanSeg inc{reset, dx, dy, cnt};
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const ScanSeg t = seg_shfl_up(inc, o);
+      if (lane >= (uint32_t)o) inc = seg_join(t, inc);
+    }
+    __syncthreads();  // s_wave / s_carry of the previous span have been read
+    if (lane == 63) s_wave[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+      ScanSeg acc = s_carry;
+      for (uint32_t w = 0; w < 16; ++w) {
+        const ScanSeg t = s_wave[w];
+        s_wave[w] = acc;
+        acc = seg_join(acc, t);
+      }
+      s_carry = ScanSeg{0, acc.x, acc.y, acc.c};
+    }
+    __syncthreads();
+    const ScanSeg before = seg_shfl_up(inc, 1);
+    const ScanSeg st = lane == 0 ? s_wave[wave] : seg_join(s_wave[wave], before);
+    int32_t x = st.x, y = st.y, c = st.c;
+#pragma unroll
+    for (uint32_t k = 0; k < SCAN_PER; ++k)
+      if (k < cntk) {
+        const uint32_t i = i0 + k;
+        if ((brk >> k) & 1u) {
+          x = y = 0;
+          c += (i == 0 && p.first_is_start) ? 0 : 1;
+        } else {
+          x += ddx[k];
+          y += ddy[k];
+        }
+        p.pos[2 * i] = x;
+        p.pos[2 * i + 1] = y;
+        p.frag[i] = (uint32_t)c;
+      }
   }
-  if (lane == 63) s_wave[wave] = inc;
   __syncthreads();
   if (tid == 0) {
-    ScanSeg acc{0, p.carry_in[0], p.carry_in[1], p.carry_in[2]};
-    for (uint32_t w = 0; w < 16; ++w) {
-      const ScanSeg t = s_wave[w];
-      s_wave[w] = acc;
-      acc = seg_join(acc, t);
-    }
-    p.carry[0] = acc.x;
-    p.carry[1] = acc.y;
-    p.carry[2] = acc.c;
-  }
-  __syncthreads();
-  const ScanSeg before = seg_shfl_up(inc, 1);
-  const ScanSeg st = lane == 0 ? s_wave[wave] : seg_join(s_wave[wave], before);
-  int32_t x = st.x, y = st.y, c = st.c;
-  for (uint32_t i = i0; i < i1; ++i) {
-    bool start = (i == 0 && p.first_is_start);
-    if (start || !p.matched[i]) {
-      x = y = 0;
-      c += start ? 0 : 1;
-    } else {
-      x += p.dxdy[2 * i];
-      y += p.dxdy[2 * i + 1];
-    }
-    p.pos[2 * i] = x;
-    p.pos[2 * i + 1] = y;
-    p.frag[i] = (uint32_t)c;
+    p.carry[0] = s_carry.x;
+    p.carry[1] = s_carry.y;
+    p.carry[2] = s_carry.c;
   }
 }
 

@@ -129,6 +129,29 @@ def test_frc_scan_matches_oracle(gpu):
     assert c2 == carry
 
 
+def test_frc_scan_long_streams_random_breaks(gpu):
+    """rmx_frc_scan on synthetic offsets: lengths around the 16 384-frame span of the kernel,
+    break densities from none to every third frame, with and without a carry."""
+    import torch
+
+    from test_pipeline_gloo import _scan
+
+    ctx = L.Context(320, 240, kmax=64)
+    rng = np.random.default_rng(17)
+    for n in (1, 2, 1023, 1025, 16383, 16384, 16385, 40000):
+        for p_break in (0.0, 0.001, 0.3):
+            matched = (rng.random(n) >= p_break).astype(np.uint8)
+            dxdy = rng.integers(-5, 6, size=(n, 2)).astype(np.int32)
+            first = bool(rng.integers(0, 2))
+            carry = ((0, 0), 0) if first else ((int(rng.integers(-99, 99)), int(rng.integers(-99, 99))), int(rng.integers(0, 9)))
+            pos, frag, cout = ctx.frc_scan(torch.from_numpy(dxdy).cuda(), torch.from_numpy(matched).cuda(),
+                                           first_is_start=first, carry=None if first else carry)
+            wp, wf, wc = _scan(dxdy, matched, first, carry)
+            assert np.array_equal(pos.cpu().numpy(), wp) and np.array_equal(frag.cpu().numpy(), wf), (n, p_break)
+            assert cout == wc, (n, p_break)
+    ctx.close()
+
+
 def test_kpm_large_tables_kmax_8192(gpu):
     # frames with thousands of keypoints (noise blocks) and a table stride above 2048
     rng = np.random.default_rng(21)
