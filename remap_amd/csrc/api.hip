@@ -30,6 +30,7 @@ struct rmx_ctx {
   // workspace (device)
   RawDesc* raw = nullptr;
   uint32_t* kraw = nullptr;
+  uint32_t* tflag = nullptr;  // per frame: left to kpe_table_rest
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
@@ -94,14 +95,17 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   if (n <= ctx->n_cap) return RMX_OK;
   if (ctx->raw) (void)hipFree(ctx->raw);
   if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->cand) (void)hipFree(ctx->cand);
   ctx->raw = nullptr;
   ctx->kraw = nullptr;
+  ctx->tflag = nullptr;
   ctx->cand = nullptr;
   ctx->n_cap = 0;
   const size_t cand_bytes = (size_t)n * ((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * sizeof(uint32_t);
   RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
   RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
+  RMX_HIP(hipMalloc(&ctx->tflag, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->cand, cand_bytes));
   ctx->n_cap = n;
   ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + cand_bytes + kpm_workspace_bytes(ctx->kpm);
@@ -202,6 +206,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->raw) (void)hipFree(ctx->raw);
+  if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->status) (void)hipFree(ctx->status);
@@ -443,7 +448,10 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   }
   {
     Timer t(ctx, &ctx->ms_table);
-    hipLaunchKernelGGL(kpe_table, dim3(n), dim3(256), lds, ctx->stream, tp);
+    tp.wave_ok = ctx->W <= 1024 && ctx->H <= 1024 && ctx->kmax <= 2048;
+    tp.left = ctx->tflag;
+    hipLaunchKernelGGL(kpe_table, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, tp);
+    hipLaunchKernelGGL(kpe_table_rest, dim3(std::min(n, 4096u)), dim3(256), lds, ctx->stream, tp);
   }
   RMX_HIP(hipGetLastError());
   return RMX_OK;

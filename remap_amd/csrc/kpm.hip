@@ -131,45 +131,6 @@ __device__ inline void umap_order_seq(const uint64_t* h, uint32_t n, uint16_t* n
   for (uint32_t p = head; p != NONE; p = next[p]) order[k++] = (OutT)p;
 }
 
-// Ascending bitonic sort of up to 64 * KPL keys held by ONE wave in registers: element i lives
-// in key[i >> 6] of lane i & 63.  Exchanges at distance < 64 are lane shuffles, larger ones
-// stay inside the lane.  n2 = power of two >= number of keys (unused elements = 0xffffffff).
-template <uint32_t KPL, uint32_t JS>
-__device__ __forceinline__ void wave_sort_inlane(uint32_t (&key)[KPL], uint32_t n2, uint32_t k) {
-#pragma unroll
-  for (uint32_t s = 0; s < KPL; ++s)
-    if ((s & JS) == 0 && (s | JS) < KPL && (s | JS) * 64 < n2) {
-      const bool up = ((s * 64) & k) == 0;
-      const uint32_t a = key[s], b = key[s | JS];
-      const uint32_t lo = min(a, b), hi = max(a, b);
-      key[s] = up ? lo : hi;
-      key[s | JS] = up ? hi : lo;
-    }
-}
-template <uint32_t KPL>
-__device__ __forceinline__ void wave_sort(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
-  static_assert(KPL == 4 || KPL == 8, "wave_sort: 4 or 8 keys per lane");
-  for (uint32_t k = 2; k <= n2; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      if (j < 64) {
-        const bool lower = (lane & j) == 0;
-#pragma unroll
-        for (uint32_t s = 0; s < KPL; ++s)
-          if (s * 64 < n2) {
-            const uint32_t other = (uint32_t)__shfl_xor((int)key[s], (int)j);
-            const bool up = ((s * 64 + lane) & k) == 0;
-            key[s] = (lower == up) ? min(key[s], other) : max(key[s], other);
-          }
-      } else if (j == 64) {
-        wave_sort_inlane<KPL, 1>(key, n2, k);
-      } else if (j == 128) {
-        wave_sort_inlane<KPL, 2>(key, n2, k);
-      } else {
-        wave_sort_inlane<KPL, 4>(key, n2, k);
-      }
-    }
-}
-
 // The same order without pointer chasing.  libstdc++ puts a node at the front of its bucket
 // and a new bucket at the front of the list, for inserts and for rehashes alike, so the list
 // after (re)building with B buckets from a sequence S is S sorted by (first position of the

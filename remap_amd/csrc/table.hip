@@ -20,6 +20,8 @@ struct TableParams {
   Bands bands;
   uint32_t H;          // frame height (scan order = x * H + y)
   uint32_t rank_words;  // ceil(W * H / 32) if the rank bitmap fits the launch's LDS, else 0
+  uint32_t wave_ok;     // frame <= 1024 x 1024 and kmax <= 2048: (x, y, index) fit a 32-bit sort key
+  uint32_t* left;       // n flags: frame not done by the wave pass
 };
 
 // In-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending; blockDim.x threads.
@@ -58,15 +60,18 @@ __device__ __forceinline__ void write_row(const TableParams& p, rmx_desc* out, u
   o[8] = (uint16_t)y;
 }
 
-// Two ways to the same table.  Few keypoints: bitonic sort of (x, y | index) keys.  Many:
-// positions are unique, so a keypoint's row is its rank in scan order — one bit per pixel in
-// an LDS bitmap indexed x * H + y, popcount prefix per thread chunk, then every record
-// computes its own row.  O(pixels / 32 + k) instead of O(k log^2 k).
-__global__ __launch_bounds__(256) void kpe_table(TableParams p) {
-  extern __shared__ uint64_t keys[];  // next_pow2(kmax) sort keys, or the rank bitmap
+// Three ways to the same table.
+//  * Up to 256 keypoints and a frame of at most 1024 x 1024 (the common case): ONE WAVE per
+//    frame sorts (x, y, index) packed into 32-bit keys in registers (wave_sort) — no LDS, no
+//    workgroup barrier, four frames per workgroup.
+//  * More keypoints: positions are unique, so a keypoint's row is its rank in scan order — one
+//    bit per pixel in an LDS bitmap indexed x * H + y, popcount prefix per thread chunk, then
+//    every record computes its own row.  O(pixels / 32 + k) instead of O(k log^2 k).
+//  * Neither fits (huge frames): bitonic sort of 64-bit keys in LDS.
+// The last two need the whole workgroup; they run after the wave pass for the frames it left.
+__device__ __forceinline__ void kpe_table_block(const TableParams& p, uint64_t* keys, uint32_t f) {
   __shared__ uint32_t chunk_pre[256];
   __shared__ uint32_t wave_tot[4];
-  const uint32_t f = blockIdx.x;
   uint32_t k = p.kcount[f];
   if (k > p.kmax) k = p.kmax;  // overflow already flagged by kpe_main
   const RawDesc* raw = p.raw + (size_t)f * p.kmax;
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
       for (uint32_t v = c * cw; v < w; ++v) rank += __popc(bm[v]);
       write_row(p, out, rank, r);
     }
+    __syncthreads();  // LDS is reused by the workgroup's next frame
     return;
   }
   uint32_t n2 = 1;
@@ -120,6 +126,55 @@ __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
   }
   bitonic_sort_u64(keys, n2);
   for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) write_row(p, out, i, raw[(uint32_t)keys[i]]);
+  __syncthreads();
+}
+
+// wave pass: four frames per workgroup, no LDS; flags the frames it leaves to the block pass
+__global__ __launch_bounds__(256) void kpe_table(TableParams p) {
+  const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+  const uint32_t f = blockIdx.x * 4 + wave;
+  if (f >= p.n) return;
+  uint32_t k = p.kcount[f];
+  if (k > p.kmax) k = p.kmax;
+  const bool mine = p.wave_ok && k <= 256;
+  if (lane == 0) p.left[f] = mine ? 0u : 1u;
+  if (!mine) return;
+  const RawDesc* raw = p.raw + (size_t)f * p.kmax;
+  rmx_desc* out = p.desc + (size_t)f * p.kmax;
+  uint32_t key[4];
+#pragma unroll
+  for (uint32_t sl = 0; sl < 4; ++sl) {
+    const uint32_t i = sl * 64 + lane;
+    key[sl] = 0xffffffffu;
+    if (i < k) {
+      const uint32_t xy = raw[i].xy;
+      key[sl] = (xy & 0xffffu) << 21 | (xy >> 16) << 11 | i;  // x (10 bits), y (10), index (11)
+    }
+  }
+  uint32_t n2 = 64;
+  while (n2 < k) n2 <<= 1;
+  wave_sort<4>(key, n2, lane);
+#pragma unroll
+  for (uint32_t sl = 0; sl < 4; ++sl) {
+    const uint32_t j = sl * 64 + lane;
+    if (j < k) write_row(p, out, j, raw[key[sl] & 0x7ffu]);
+  }
+  if (lane == 0) p.kout[f] = k;
+}
+
+// block pass: a fixed grid; workgroup b looks at the flags of frames b, b + G, b + 2G, ... side
+// by side and walks only the flagged ones (an all-sparse batch costs the launch, nothing more)
+__global__ __launch_bounds__(256) void kpe_table_rest(TableParams p) {
+  extern __shared__ uint64_t keys[];  // the rank bitmap, or sort keys
+  const uint32_t G = gridDim.x, b = blockIdx.x;
+  const uint32_t K = b < p.n ? (p.n - b + G - 1) / G : 0;
+  for (uint32_t base = 0; base < K; base += 256) {
+    const uint32_t kk = base + threadIdx.x;
+    if (!__syncthreads_or(kk < K && p.left[b + kk * G] != 0)) continue;
+    const uint32_t end = min(K, base + 256);
+    for (uint32_t q = base; q < end; ++q)
+      if (p.left[b + q * G]) kpe_table_block(p, keys, b + q * G);  // uniform for the workgroup
+  }
 }
 
 }  // namespace rmx
