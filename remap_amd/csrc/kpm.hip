@@ -596,14 +596,26 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     __builtin_amdgcn_wave_barrier();
     // 3. order entries by (first occurrence of their code, scan order): bitonic sort of one key per lane
     if (lane < e) key = htl[r][myslot] << 16 | lane;
+    // (unused lanes hold 0xffffffff; a region of the sparse stream has ~10 entries: 16 lanes, 10 steps)
+    if (e <= 16) {
 #pragma unroll
-    for (uint32_t kk = 2; kk <= 64; kk <<= 1)
+      for (uint32_t kk = 2; kk <= 16; kk <<= 1)
 #pragma unroll
-      for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-        uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
-        bool up = (lane & kk) == 0, lower = (lane & j) == 0;
-        key = (lower == up) ? min(key, other) : max(key, other);
-      }
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
+          bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+          key = (lower == up) ? min(key, other) : max(key, other);
+        }
+    } else {
+#pragma unroll
+      for (uint32_t kk = 2; kk <= 64; kk <<= 1)
+#pragma unroll
+        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
+          uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
+          bool up = (lane & kk) == 0, lower = (lane & j) == 0;
+          key = (lower == up) ? min(key, other) : max(key, other);
+        }
+    }
     // 4. groups in first-occurrence order
     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
     start = lane < e && (lane == 0 || (key >> 16) != (prev >> 16));
