@@ -72,3 +72,71 @@ def test_two_ranks_collect_sum_splice_equal_reference(gpu):
             assert csum == int(g["canvas_sum"][k]), (rank, k)
             for no, p in fr:
                 assert int(g["frag"][no]) == k and list(p) == g["pos"][no].tolist(), (rank, k, no)
+
+
+def _worker_align(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from remap_amd.pipeline import Aligner, shard_range
+    from remap_amd.synth import scroller_v1
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _broken_stream()
+    n = len(frames)
+    lo, hi = shard_range(n, rank, world)
+    al = Aligner(320, 240, kmax=2048, dist=dist)
+    out = al.align(torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda(), n_total=n, blit=True)
+    q.put((rank, lo, hi, out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy(), out["pos"].cpu().numpy(),
+           out["frag"].cpu().numpy(), out["pos_all"].cpu().numpy(), out["frag_all"].cpu().numpy(), out["nfrag"]))
+    al.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _broken_stream():
+    from remap_amd.synth import scroller_v1
+
+    frames, _ = scroller_v1(203, dens=120)
+    frames = frames.copy()
+    for i in (50, 51, 101, 150):  # breaks inside blocks and exactly at a block edge of the 4-rank cut
+        frames[i] = 6
+    return frames
+
+
+@pytest.mark.timeout(600)
+def test_four_ranks_equal_single_process_bit_for_bit(gpu):
+    """Config 3 in miniature: the frame-sharded alignment (4 ranks, uneven blocks, fragment
+    breaks at and inside block edges) gives every rank exactly the single-process offsets,
+    positions and fragment ids for its frames, and the same whole-stream view."""
+    import torch
+    import torch.multiprocessing as mp
+
+    from remap_amd.pipeline import Aligner
+
+    frames = _broken_stream()
+    al = Aligner(320, 240, kmax=2048)
+    ref = al.align(torch.from_numpy(frames).cuda())
+    want = {k: ref[k].cpu().numpy() for k in ("dxdy", "matched", "pos", "frag")}
+    nfrag = ref["nfrag"]
+    al.close()
+    assert nfrag >= 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_align, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, lo, hi, dxdy, matched, pos, frag, pos_all, frag_all, nf in res:
+        first = 1 if rank == 0 else 0
+        assert np.array_equal(matched, want["matched"][lo:hi]), rank
+        assert np.array_equal(dxdy[first:], want["dxdy"][lo + first:hi]), rank
+        assert np.array_equal(pos, want["pos"][lo:hi]) and np.array_equal(frag, want["frag"][lo:hi]), rank
+        assert np.array_equal(pos_all, want["pos"]) and np.array_equal(frag_all, want["frag"]), rank
+        assert nf == nfrag
