@@ -270,13 +270,17 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       mraw = 0;
       sh = 8;
       if (i >= m) return;
-      const uint32_t g = list[i];
-      const int fx = X - list_ax[i], fy = Y - list_ay[i];
+      // the frame and its canvas origin are the same for the whole workgroup: scalar registers,
+      // scalar arithmetic for the frame's base address
+      const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]);
+      const int ax = __builtin_amdgcn_readfirstlane(list_ax[i]), ay = __builtin_amdgcn_readfirstlane(list_ay[i]);
+      const int fx = X - ax, fy = Y - ay;
       if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return;
       const int fxc = min(max(fx, 0), W - 4);
-      const size_t off = ((size_t)g * H + (size_t)fy) * W + (size_t)fxc;
-      __builtin_memcpy(&raw, p.frames + off, 4);  // unaligned dword
-      if (p.mask) __builtin_memcpy(&mraw, p.mask + off, 4);
+      const size_t fbase = (size_t)g * (size_t)(H * W);
+      const uint32_t off = (uint32_t)(fy * W + fxc);
+      __builtin_memcpy(&raw, p.frames + fbase + off, 4);  // unaligned dword
+      if (p.mask) __builtin_memcpy(&mraw, p.mask + fbase + off, 4);
       sh = fx - fxc;
     };
     auto place = [](uint32_t w, int sh, uint32_t fill) {  // bytes of the clamped dword -> pixel order, `fill` elsewhere
