@@ -313,10 +313,16 @@ __global__ __launch_bounds__(256) void nic_pack(NicPackParams p) {
   for (uint32_t i = threadIdx.x; i < n; i += 256) dst[i] = src[i];
 }
 
-// nic::decompress (nic.hpp:103-164): one wave per image.  Tokens are variable-length, so the
-// parse is sequential — every lane walks the same token stream (uniform loads) — while the
-// pixels of each token are written by all lanes side by side.  Parallelism comes from the
-// batch (thousands of images in flight).
+// nic::decompress (nic.hpp:103-164): one wave per image.  Token lengths chain through the
+// stream, but everything else is done side by side.  Per 64-byte chunk of the stream (read from
+// an LDS window): every lane parses the token that WOULD start at its byte; six rounds of
+// pointer doubling over those speculative "next token" links mark the real starts and give the
+// chunk's exit; wave scans of the real tokens' pixel and piece counts place them; the output is
+// cut into 16-pixel pieces handed to the lanes (each finds its token by a 6-step search over the
+// piece counts and writes its piece with one unaligned 16-byte store, or 8+4+2+1 for a token's
+// tail); tokens over 1024 pixels are written by the whole wave.  History (10 000 sparse 320x240
+// images, ~4 100 tokens each): one token per trip with uniform loads 5.5 ms; lane-parallel parse
+// with a scalar walk and a per-token wave loop for runs over 8 pixels 9.7 ms.
 struct NicDecParams {
   const uint8_t* packed;
   const uint64_t* offsets;
@@ -325,57 +331,200 @@ struct NicDecParams {
   uint32_t* status;
   uint32_t n, pixels;
 };
+constexpr uint32_t NIC_WIN = 4096;  // bytes of stream kept in LDS
+constexpr uint32_t NIC_BIG = 1024;  // tokens of more pixels are written by the whole wave
+constexpr uint32_t NIC_AHEAD = 64 + 2 + NIC_BIG / 2 + 8;  // window bytes a chunk may touch from its first byte
+
+// All lanes fill `len` bytes at `dst` with `v`: bytes up to 16-byte alignment, uint4 body, bytes.
+__device__ __forceinline__ void nic_wave_fill(uint8_t* dst, uint32_t len, uint32_t v, uint32_t lane) {
+  const uint32_t head = min(len, (uint32_t)(-(intptr_t)reinterpret_cast<uintptr_t>(dst)) & 15u);
+  if (lane < head) dst[lane] = (uint8_t)v;
+  const uint32_t nvec = (len - head) >> 4;
+  const uint32_t w = v * 0x01010101u;
+  uint4* body = reinterpret_cast<uint4*>(dst + head);
+  for (uint32_t j = lane; j < nvec; j += 64) body[j] = make_uint4(w, w, w, w);
+  const uint32_t done = head + 16 * nvec;
+  if (lane < len - done) dst[done + lane] = (uint8_t)v;
+}
+
 __global__ __launch_bounds__(64) void nic_decompress(NicDecParams p) {
+  __shared__ uint32_t win[NIC_WIN / 4 + 2];
+  __shared__ uint32_t reach[64];
   const uint32_t f = blockIdx.x, lane = threadIdx.x;
   const uint8_t* src = p.packed + p.offsets[f];
   const uint32_t size = p.sizes[f];
   uint8_t* out = p.images + (size_t)f * p.pixels;
+  const int32_t mis = (int32_t)(reinterpret_cast<uintptr_t>(src) & 3u);  // window words are aligned dwords of memory
+  int32_t wbase = INT32_MIN;  // stream offset of win[0]; -3..-1 when the stream starts inside its first dword
   uint32_t i = 0, o = 0;
-  bool bad = false;
-  while (i < size) {
-    const uint32_t t = src[i];
-    if ((t & 0x80u) == 0) {  // REP
-      uint32_t len, nb = 0;
-      if ((t & 0x40u) == 0) {
-        len = (t >> 4) + 3;
-      } else {
-        nb = (t >> 4) & 3u;
-        if (i + nb >= size) {
-          bad = true;
-          break;
-        }
-        len = 0;
-        for (uint32_t b = 0; b < nb; ++b) len |= (uint32_t)src[i + 1 + b] << (8 * b);
+  bool bad = size >= 0x7fff0000u;
+  auto lds_sync = [] {  // one wave: LDS is in order, only the compiler has to be told
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto refill = [&](uint32_t k) {  // window from byte k on (uniform)
+    wbase = ((int32_t)k + mis) / 4 * 4 - mis;
+    lds_sync();
+    const uint8_t* g = src + wbase;  // 4-byte aligned
+    const int32_t avail = (int32_t)size - wbase;  // bytes of the stream from win[0] on
+    for (uint32_t w = lane; w < NIC_WIN / 4 && (int32_t)(4 * w) < avail; w += 64) {
+      uint32_t v;
+      if ((int32_t)(4 * w + 4) <= avail) {
+        v = *reinterpret_cast<const uint32_t*>(g + 4 * w);
+      } else {  // the stream ends inside this dword: nothing past its last byte is touched
+        v = 0;
+        for (int32_t b = 0; (int32_t)(4 * w) + b < avail; ++b) v |= (uint32_t)g[4 * w + b] << (8 * b);
       }
-      i += 1 + nb;
-      if (o + len > p.pixels) {
-        bad = true;
-        break;
-      }
-      for (uint32_t j = lane; j < len; j += 64) out[o + j] = (uint8_t)(t & 15u);
-      o += len;
-    } else {  // LITERAL
-      uint32_t n = t & 0x3fu;
-      ++i;
-      if (t & 0x40u) {
-        if (i >= size) {
-          bad = true;
-          break;
-        }
-        n = (n << 8) + src[i++];
-      }
-      const uint32_t nbytes = (n + 1) >> 1;
-      if (i + nbytes > size || o + n > p.pixels) {
-        bad = true;
-        break;
-      }
-      for (uint32_t j = lane; j < n; j += 64) {
-        const uint32_t b = src[i + (j >> 1)];
-        out[o + j] = (uint8_t)((j & 1u) ? (b & 15u) : (b >> 4));
-      }
-      i += nbytes;
-      o += n;
+      win[w] = v;
     }
+    lds_sync();
+  };
+  auto dword_at = [&](uint32_t k) -> uint32_t {  // stream bytes k..k+3 out of the window
+    const uint32_t r = min((uint32_t)((int32_t)k - wbase), NIC_WIN);
+    return __builtin_amdgcn_alignbyte(win[(r >> 2) + 1], win[r >> 2], r & 3u);
+  };
+  while (!bad && i < size) {
+    if ((int32_t)i < wbase || (int64_t)i + NIC_AHEAD > (int64_t)wbase + NIC_WIN) refill(i);
+    // ---- the token that would start at byte i + lane ----
+    const uint32_t k = i + lane;
+    const uint32_t hv = dword_at(k);
+    const uint32_t t = hv & 0xffu;
+    const bool lit = (t & 0x80u) != 0;
+    uint32_t tl, px;
+    bool ok = k < size;
+    if (!lit) {
+      const uint32_t nb = (t & 0x40u) ? (t >> 4) & 3u : 0u;
+      tl = 1 + nb;
+      px = (t & 0x40u) ? (hv >> 8) & (nb ? 0xffffffu >> (8 * (3 - nb)) : 0u) : (t >> 4) + 3;
+      ok = ok && k + nb < size;
+    } else {
+      px = t & 0x3fu;
+      tl = 1;
+      if (t & 0x40u) {
+        px = (px << 8) + ((hv >> 8) & 0xffu);
+        tl = 2;
+      }
+      tl += (px + 1) >> 1;
+      ok = ok && (uint64_t)k + tl <= size;
+    }
+    // ---- the real token starts: pointer doubling over "next token" from lane 0 ----
+    // link < 64: a lane of this chunk; otherwise absorbing: the chunk's exit offset, 0x10000 = a
+    // broken token, 0x20000 + lane = the end of the stream
+    uint32_t link = ok ? lane + tl : (k < size ? 0x10000u : 0x20000u + lane);
+    reach[lane] = lane == 0;
+#pragma unroll
+    for (int round = 0; round < 6; ++round) {
+      lds_sync();
+      const uint32_t r = reach[lane];
+      if (r && link < 64) reach[link] = 1;
+      const uint32_t far = (uint32_t)__shfl((int)link, (int)(link & 63u));
+      if (link < 64) link = far;
+    }
+    lds_sync();
+    const bool mine = reach[lane] != 0 && k < size;
+    const uint32_t exit_code = (uint32_t)__builtin_amdgcn_readlane((int)link, 0);
+    if (exit_code == 0x10000u) {
+      bad = true;
+      break;
+    }
+    const uint32_t pos = exit_code >= 0x20000u ? exit_code - 0x20000u : exit_code;
+    // ---- placement: scans of the real tokens' pixels and 16-pixel pieces ----
+    const bool big = mine && px > NIC_BIG;
+    uint32_t ipx = mine ? px : 0u;
+    uint32_t ipc = (mine && !big) ? (px + 15) >> 4 : 0u;
+#pragma unroll
+    for (uint32_t d = 1; d < 64; d <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)ipx, d), v = (uint32_t)__shfl_up((int)ipc, d);
+      if (lane >= d) {
+        ipx += u;
+        ipc += v;
+      }
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)ipx, 63);
+    const uint32_t pieces = (uint32_t)__builtin_amdgcn_readlane((int)ipc, 63);
+    if (total > p.pixels - o) {
+      bad = true;
+      break;
+    }
+    const uint32_t epx = ipx - (mine ? px : 0u);  // pixel offset of my token in the chunk
+    // ---- pieces: lane w writes piece w ----
+    for (uint32_t base = 0; base < pieces; base += 64) {
+      const uint32_t w = base + lane;
+      uint32_t s = 0;  // the first lane whose inclusive piece count exceeds w: the piece's token
+#pragma unroll
+      for (uint32_t step = 32; step > 0; step >>= 1) {
+        const uint32_t v = (uint32_t)__shfl((int)ipc, (int)(s + step - 1));
+        if (v <= w) s += step;
+      }
+      s = min(s, 63u);
+      const uint32_t spx = (uint32_t)__shfl((int)px, (int)s);
+      const uint32_t shv = (uint32_t)__shfl((int)hv, (int)s);
+      const uint32_t sepx = (uint32_t)__shfl((int)epx, (int)s);
+      const uint32_t sipc = (uint32_t)__shfl((int)ipc, (int)s);
+      if (w < pieces) {
+        const uint32_t pi = w - (sipc - ((spx + 15) >> 4));
+        uint32_t cnt = min(16u, spx - 16 * pi);
+        uint8_t* d = out + o + sepx + 16 * pi;
+        uint32_t d0, d1, d2, d3;
+        if ((shv & 0x80u) == 0) {
+          d0 = d1 = d2 = d3 = (shv & 15u) * 0x01010101u;
+        } else {  // 8 payload bytes, high nibble first
+          const uint32_t at = i + s + ((shv & 0x40u) ? 2u : 1u) + 8 * pi;
+          const uint32_t x0 = dword_at(at), x1 = dword_at(at + 4);
+          const uint32_t e0 = (x0 >> 4) & 0x0f0f0f0fu, o0 = x0 & 0x0f0f0f0fu;
+          const uint32_t e1 = (x1 >> 4) & 0x0f0f0f0fu, o1 = x1 & 0x0f0f0f0fu;
+          d0 = perm(o0, e0, 0x05010400u);
+          d1 = perm(o0, e0, 0x07030602u);
+          d2 = perm(o1, e1, 0x05010400u);
+          d3 = perm(o1, e1, 0x07030602u);
+        }
+        if (cnt == 16) {
+          const uint4 v = make_uint4(d0, d1, d2, d3);
+          __builtin_memcpy(d, &v, 16);  // unaligned global_store_dwordx4
+        } else {
+          if (cnt & 8u) {
+            const uint2 v = make_uint2(d0, d1);
+            __builtin_memcpy(d, &v, 8);
+            d0 = d2;
+            d1 = d3;
+            d += 8;
+          }
+          if (cnt & 4u) {
+            __builtin_memcpy(d, &d0, 4);
+            d0 = d1;
+            d += 4;
+          }
+          if (cnt & 2u) {
+            const uint16_t v = (uint16_t)d0;
+            __builtin_memcpy(d, &v, 2);
+            d0 >>= 16;
+            d += 2;
+          }
+          if (cnt & 1u) *d = (uint8_t)d0;
+        }
+      }
+    }
+    // ---- tokens over NIC_BIG pixels: the whole wave writes each ----
+    uint64_t bigs = __ballot(big);
+    while (bigs) {
+      const int sl = __builtin_ctzll(bigs);
+      bigs &= bigs - 1;
+      const uint32_t lt = (uint32_t)__builtin_amdgcn_readlane((int)t, sl);
+      const uint32_t ln = (uint32_t)__builtin_amdgcn_readlane((int)px, sl);
+      uint8_t* d = out + o + (uint32_t)__builtin_amdgcn_readlane((int)epx, sl);
+      if ((lt & 0x80u) == 0) {
+        nic_wave_fill(d, ln, lt & 15u, lane);
+      } else {
+        const uint8_t* pay = src + i + (uint32_t)sl + ((lt & 0x40u) ? 2u : 1u);
+        for (uint32_t j = lane; 2 * j < ln; j += 64) {  // a payload byte = two pixels per lane
+          const uint32_t b = pay[j];
+          d[2 * j] = (uint8_t)(b >> 4);
+          if (2 * j + 1 < ln) d[2 * j + 1] = (uint8_t)(b & 15u);
+        }
+      }
+    }
+    o += total;
+    i += pos;
   }
   if ((bad || o != p.pixels) && lane == 0) atomicOr(&p.status[2], 2u);  // malformed stream / wrong pixel count
 }

@@ -114,3 +114,65 @@ def test_nic_decompress_golden_streams_and_round_trip(gpu):
     with pytest.raises(L.RemapError):
         ctx.nic_decompress(packed, [int(sizes[0])], 320 * 240 - 5)
     ctx.close()
+
+
+def _random_stream(rng, kinds):
+    """A valid token stream of every header form (nic.hpp:103-164) and the pixels it decodes to."""
+    toks, px = [], []
+    for _ in range(int(rng.integers(1, 400))):
+        kind = kinds[int(rng.integers(len(kinds)))]
+        v = int(rng.integers(16))
+        if kind == "r1":
+            n = int(rng.integers(3, 7))
+            toks.append(bytes([(n - 3) << 4 | v]))
+        elif kind == "r2":
+            n = int(rng.integers(0, 256))
+            toks.append(bytes([0x50 | v, n]))
+        elif kind == "r3":
+            n = int(rng.integers(0, 3000))
+            toks.append(bytes([0x60 | v, n & 255, n >> 8]))
+        elif kind == "r0":
+            n = 0
+            toks.append(bytes([0x40 | v]))
+        if kind[0] == "r":
+            px.append(np.full(n, v, np.uint8))
+            continue
+        n = int(rng.integers(0, 64)) if kind == "l1" else int(rng.integers(0, 700))
+        p = rng.integers(0, 16, size=n, dtype=np.uint8)
+        q = np.concatenate([p, np.zeros(n & 1, np.uint8)])
+        body = bytes((q[0::2] << 4 | q[1::2]).astype(np.uint8))
+        toks.append((bytes([0x80 | n]) if kind == "l1" else bytes([0xc0 | n >> 8, n & 255])) + body)
+        px.append(p)
+    return b"".join(toks), np.concatenate(px)
+
+
+def test_nic_decompress_random_token_streams(gpu):
+    """Every header form, zero-length tokens, tokens across the 64-byte chunk and 4-KB window
+    edges, blobs at odd offsets: the decoder equals the oracle's on each stream."""
+    import torch
+
+    rng = np.random.default_rng(77)
+    ctx = L.Context(16, 8, grid=(1, 1), overlap=0, kmax=64)
+    mixes = [("r1",), ("r1", "l1"), ("r1", "r2", "r3", "r0", "l1", "l2"), ("l1", "l2"), ("r3", "l2"), ("r1", "r1", "r1", "l1", "r2")]
+    for rep in range(24):
+        streams = [_random_stream(rng, mixes[(rep + j) % len(mixes)]) for j in range(9)]
+        for blob, pix in streams:
+            dec, cnt = O.orc_nic_decompress(blob, len(pix))
+            assert cnt == len(pix) and np.array_equal(dec, pix)
+        # one launch decodes images of one pixel count: pad each stream with runs up to the longest
+        P = max(len(p) for _, p in streams) + 7
+        blobs, want = [], []
+        for blob, pix in streams:
+            pad = P - len(pix)
+            tail = b""
+            while pad > 0:
+                n = min(pad, 255) if pad >= 3 else pad
+                tail += bytes([0x50 | 3, n])
+                pad -= n
+            blobs.append(blob + tail)
+            want.append(np.concatenate([pix, np.full(P - len(pix), 3, np.uint8)]))
+        packed = torch.from_numpy(np.frombuffer(b"".join(blobs), np.uint8).copy()).cuda()
+        out = ctx.nic_decompress(packed, [len(b) for b in blobs], P).cpu().numpy()
+        for j, w in enumerate(want):
+            assert np.array_equal(out[j], w), (rep, j)
+    ctx.close()

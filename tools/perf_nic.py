@@ -21,3 +21,13 @@ for name, plane in (("frames", d), ("medians", med)):
     tot = int(sizes.sum().item())
     print(f"{name}: {ms:.3f} ms per {N} images, {N / ms / 1e3:.2f} M images/s, in {plane.numel() / ms / 1e6:.0f} GB/s, "
           f"out {tot / N:.0f} B/image (ratio {plane.numel() / tot:.1f})")
+# decode: rmx_nic_decompress_batch of the packed frame blobs
+packed, sizes = c.nic_compress(d.reshape(N, -1))
+back = c.nic_decompress(packed, sizes, 320 * 240)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(3):
+    back = c.nic_decompress(packed, sizes, 320 * 240)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 3
+print(f"decompress: {dt * 1e3:.2f} ms per {N} images (wall, incl. offset upload), round trip exact: {bool(torch.equal(back, d.reshape(N, -1)))}")
