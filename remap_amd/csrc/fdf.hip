@@ -6,11 +6,13 @@
 // background (its blended canvas), keeps the components of at most W*H/5 pixels, and masks
 // their pixels plus their bounding boxes out of a second blit of the frame.  What it computes
 // is order-free except for one quirk (below), so here it is a connected-component labelling:
-//   fdf_init     label = own index for interior pixels (rows 1..H-3, columns 1..W-2: the
-//                reference's "horizon" ring includes row H-2, cte.hpp:149-166), statistics reset
-//   fdf_merge    union-find over left/up neighbours of equal median colour (atomicMin on roots)
-//   fdf_stats    labels flattened to roots; area / bounding box / seeded per root, atomics
-//                aggregated over runs of equal roots inside a wave
+//   fdf_local    a workgroup labels one strip of rows of one frame in LDS: run labels from a
+//                ballot, a union-find (ds atomics) over the runs of the strip, labels flattened
+//                to the strip's roots (rows 1..H-3, columns 1..W-2 only: the reference's
+//                "horizon" ring includes row H-2, cte.hpp:149-166); statistics reset
+//   fdf_stitch   unions across the strip boundaries (global atomicMin on the strips' roots)
+//   fdf_stats    labels flattened to roots; area / seeded per root, atomics aggregated over
+//                runs of equal roots inside a wave
 //   fdf_keep     roots that are seeded and small enough -> per-frame list; mask = own pixels
 //   fdf_boxes    one wave per kept component: the box's left side as cdt::limits::update
 //                leaves it (cdt.hpp:183-190: `else if` — the smallest left/right-edge x that is
@@ -31,46 +33,22 @@ struct FdfParams {
   uint32_t* ncontours;    // n out (may be null)
   // workspace, per frame P = W*H entries
   uint32_t* label;
-  uint32_t* area;
+  uint32_t* area;  // per root: pixels | FDF_SEEDED
   uint32_t* minx;
   uint32_t* maxx;
   uint32_t* miny;
   uint32_t* maxy;
-  uint8_t* seeded;
   uint32_t* kept;  // per frame: [0] = count, [1..cap] root indices
   uint32_t* status;
   uint32_t n, W, H, bw, bh, kept_cap;
 };
 
 constexpr uint32_t FDF_NONE = 0xffffffffu;
+constexpr uint32_t FDF_SEEDED = 0x80000000u;  // bit 31 of a root's area word: one of its pixels differs from the background
 constexpr uint32_t FDF_KEPT_CAP = 4096;  // kept components per frame the list holds (more -> RMX_ERR_CAPACITY)
 
 __device__ __forceinline__ bool fdf_interior(const FdfParams& p, uint32_t x, uint32_t y) {
   return x >= 1 && x + 1 < p.W && y >= 1 && y + 2 < p.H;
-}
-
-// Labels start as "leftmost pixel of my run of equal colour inside my wave" (a ballot, no
-// memory traffic), so the union-find only has to stitch runs: across wave boundaries and
-// between rows, once per pair of overlapping runs (fdf_merge).  A per-pixel union with the
-// left neighbour makes chains as long as the flat areas are wide: 7.5 ms vs 0.86 ms per 800 frames.
-__global__ __launch_bounds__(256) void fdf_init(FdfParams p) {
-  const uint32_t P = p.W * p.H;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = g < (size_t)p.n * P;
-  const uint32_t i = live ? (uint32_t)(g % P) : 0, x = i % p.W, y = i / p.W, lane = threadIdx.x & 63u;
-  const bool in = live && fdf_interior(p, x, y);
-  const bool left_same = in && x >= 2 && p.median[g - 1] == p.median[g];
-  const uint64_t heads = __builtin_amdgcn_ballot_w64(!left_same || lane == 0);
-  if (!live) return;
-  const uint32_t start = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));  // last head at or before me
-  p.label[g] = in ? i - (lane - start) : FDF_NONE;
-  p.area[g] = 0;
-  p.minx[g] = FDF_NONE;
-  p.maxx[g] = 0;
-  p.miny[g] = FDF_NONE;
-  p.maxy[g] = 0;
-  p.seeded[g] = 0;
-  if (i == 0) p.kept[(size_t)(g / P) * (p.kept_cap + 1)] = 0;
 }
 
 __device__ __forceinline__ uint32_t fdf_find(const uint32_t* L, uint32_t a) {
@@ -96,24 +74,6 @@ __device__ __forceinline__ void fdf_union(uint32_t* L, uint32_t a, uint32_t b) {
   }
 }
 
-__global__ __launch_bounds__(256) void fdf_merge(FdfParams p) {
-  const uint32_t P = p.W * p.H;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (g >= (size_t)p.n * P) return;
-  const uint32_t i = (uint32_t)(g % P), x = i % p.W, y = i / p.W;
-  if (!fdf_interior(p, x, y)) return;
-  const size_t f0 = g - i;
-  const uint8_t* med = p.median + f0;
-  uint32_t* L = p.label + f0;
-  const uint8_t c = med[i];
-  const bool left_same = x >= 2 && med[i - 1] == c;
-  // a run that continues across a wave boundary
-  if (left_same && (threadIdx.x & 63u) == 0) fdf_union(L, i, i - 1);
-  // the run above: once per pair of overlapping runs — if my left neighbour continues my run
-  // and its upper neighbour continues the upper run, that pixel (or one further left) does it
-  if (y >= 2 && med[i - p.W] == c && !(left_same && med[i - p.W - 1] == c)) fdf_union(L, i, i - p.W);
-}
-
 // Lanes hold consecutive pixels.  True on the first lane of every run of lanes with the same
 // root in the same row; len = lanes in that run (inside this wave).  All lanes must call.
 __device__ __forceinline__ bool fdf_run_head(uint32_t root, uint32_t x, uint32_t& len) {
@@ -127,51 +87,211 @@ __device__ __forceinline__ bool fdf_run_head(uint32_t root, uint32_t x, uint32_t
   return head;
 }
 
+// Strip-local labelling.  Labels start as "leftmost pixel of my run of equal colour inside my
+// wave" (a ballot, no memory traffic), so the union-find only has to stitch runs: across wave
+// boundaries and between rows, once per pair of overlapping runs.  (A per-pixel union with the
+// left neighbour makes chains as long as the flat areas are wide.)  All of it runs on LDS; HBM
+// sees one read of the medians and one write of the labels.  History per 833 frames 320x240:
+// whole-frame union-find in HBM with one thread per pixel: init 268 + merge 856 us, and 700 us
+// for fdf_stats to walk the chains it left.
+#ifndef FDF_TILE_PX
+#define FDF_TILE_PX 7680
+#endif
+constexpr uint32_t FDF_TILE = FDF_TILE_PX;  // pixels of a strip (5 B of LDS each: 37.5 KB, four workgroups per CU)
+
+__global__ __launch_bounds__(256) void fdf_local(FdfParams p, uint32_t R, uint32_t S) {
+  __shared__ uint32_t lab[FDF_TILE];
+  __shared__ uint8_t col[FDF_TILE];
+  const uint32_t f = blockIdx.x / S, s = blockIdx.x - f * S, tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t W = p.W, P = p.W * p.H;
+  const uint32_t ys = 1 + s * R, ye = min(ys + R, p.H >= 2 ? p.H - 2 : 0u);  // interior rows [ys, ye)
+  const uint32_t npx = ye > ys ? (ye - ys) * W : 0u, base = ys * W;
+  const size_t f0 = (size_t)f * P;
+  if (s == 0 && tid == 0) p.kept[(size_t)f * (p.kept_cap + 1)] = 0;
+  const uint8_t* med = p.median + f0 + base;
+  for (uint32_t t = tid; t < npx; t += 256) col[t] = med[t];
+  __syncthreads();
+  // (x of a thread's pixels without a division per pixel: t advances by 256)
+  const uint32_t xstep = 256u % W;
+  auto next_x = [&](uint32_t x) { return x + xstep >= W ? x + xstep - W : x + xstep; };
+  // 1. run labels; a label that points at itself may become a root: reset its statistics
+  for (uint32_t t0 = 0, x = tid % W; t0 < npx; t0 += 256, x = next_x(x)) {
+    const uint32_t t = t0 + tid;
+    const bool live = t < npx;
+    const bool in = live && x >= 1 && x + 1 < W;
+    const bool left_same = in && x >= 2 && col[t - 1] == col[t];
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(!left_same || lane == 0);
+    const uint32_t start = 63u - (uint32_t)__builtin_clzll(heads & (~0ull >> (63u - lane)));  // last head at or before me
+    if (live) {
+      const uint32_t l = in ? t - (lane - start) : FDF_NONE;
+      lab[t] = l;
+      if (l == t) {
+        const size_t g = f0 + base + t;
+        p.area[g] = 0;  // (one scattered store per run; the bounding boxes are reset by fdf_stats, for roots only)
+      }
+    }
+  }
+  __syncthreads();
+  // 2. unions inside the strip
+  for (uint32_t t = tid, x = tid % W; t < npx; t += 256, x = next_x(x)) {
+    if (x < 1 || x + 1 >= W) continue;
+    const uint8_t c = col[t];
+    const bool left_same = x >= 2 && col[t - 1] == c;
+    // a run that continues across a wave boundary
+    if (left_same && lane == 0) fdf_union(lab, t, t - 1);
+    // the run above: once per pair of overlapping runs — if my left neighbour continues my run
+    // and its upper neighbour continues the upper run, that pixel (or one further left) does it
+    if (t >= W && col[t - W] == c && !(left_same && col[t - W - 1] == c)) fdf_union(lab, t, t - W);
+  }
+  __syncthreads();
+  // 3. labels to the strip's roots (frame-relative pixel index)
+  for (uint32_t t = tid, x = tid % W; t < npx; t += 256, x = next_x(x))
+    p.label[f0 + base + t] = (x >= 1 && x + 1 < W) ? base + fdf_find(lab, t) : FDF_NONE;
+}
+
+// First row of every strip but the first against the row above it.
+__global__ __launch_bounds__(256) void fdf_stitch(FdfParams p, uint32_t R, uint32_t S) {
+  const uint32_t W = p.W, P = p.W * p.H;
+  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t per_frame = (size_t)(S - 1) * W;
+  if (g >= (size_t)p.n * per_frame) return;
+  const uint32_t f = (uint32_t)(g / per_frame), rest = (uint32_t)(g % per_frame), s = 1 + rest / W, x = rest % W;
+  const uint32_t y = 1 + s * R;
+  if (!fdf_interior(p, x, y)) return;
+  const size_t f0 = (size_t)f * P;
+  const uint8_t* med = p.median + f0;
+  const uint32_t i = y * W + x;
+  const uint8_t c = med[i];
+  if (med[i - W] == c && !(x >= 2 && med[i - 1] == c && med[i - W - 1] == c)) fdf_union(p.label + f0, i, i - W);
+}
+
+// fdf_stats and fdf_keep walk label -> root -> statistics: chains of dependent loads.  A thread
+// takes FDF_PPT pixels (256 apart, so a wave still holds 64 consecutive pixels of each) and
+// issues the loads of all of them side by side (one pixel per thread: 645 / 247 us per 833 frames).
+constexpr uint32_t FDF_PPT = 4;
+
 __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
   const uint32_t P = p.W * p.H;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = g < (size_t)p.n * P;
-  const uint32_t i = live ? (uint32_t)(g % P) : 0, x = i % p.W, y = i / p.W;
-  const size_t f0 = g - i;
-  uint32_t root = FDF_NONE;
-  if (live && fdf_interior(p, x, y)) {
-    root = fdf_find(p.label + f0, i);
-    p.label[g] = root;  // (a pixel only ever shortens its own chain)
-    const int32_t bx = p.pos[2 * (g / P)], by = p.pos[2 * (g / P) + 1];
-    if (p.frames[g] != p.bg[(size_t)(by + (int32_t)y) * p.bw + (size_t)(bx + (int32_t)x)]) p.seeded[f0 + root] = 1;
+  const size_t total = (size_t)p.n * P;
+  size_t g[FDF_PPT], f0[FDF_PPT];
+  uint32_t x[FDF_PPT], y[FDF_PPT], a[FDF_PPT];
+  bool in[FDF_PPT];
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) {
+    g[k] = ((size_t)blockIdx.x * FDF_PPT + k) * 256 + threadIdx.x;
+    const bool live = g[k] < total;
+    const uint32_t i = live ? (uint32_t)(g[k] % P) : 0u;
+    x[k] = i % p.W;
+    y[k] = i / p.W;
+    f0[k] = g[k] - i;
+    in[k] = live && fdf_interior(p, x[k], y[k]);
+    a[k] = in[k] ? i : FDF_NONE;
   }
-  // runs of equal roots along a row inside the wave: the run's first lane adds for all.  Only
-  // the area here — a frame's big background component takes thousands of these per frame on
-  // one address; its bounding box is never needed (fdf_keep adds boxes of kept components only)
-  uint32_t len;
-  if (fdf_run_head(root, x, len)) atomicAdd(&p.area[f0 + root], len);
+  // all chains one step at a time
+  for (;;) {
+    uint32_t q[FDF_PPT];
+    bool moved = false;
+#pragma unroll
+    for (uint32_t k = 0; k < FDF_PPT; ++k) q[k] = in[k] ? p.label[f0[k] + a[k]] : a[k];
+#pragma unroll
+    for (uint32_t k = 0; k < FDF_PPT; ++k) {
+      moved = moved || q[k] != a[k];
+      a[k] = q[k];
+    }
+    if (!moved) break;
+  }
+  // the root of the workgroup's first pixel is usually the frame's background, which collects
+  // over a thousand run lengths per frame on one address: those of this workgroup meet in LDS
+  __shared__ size_t s_hot;
+  __shared__ uint32_t s_sum;
+  if (threadIdx.x < 64) {  // the first interior pixel of the first wave
+    const uint64_t any = __builtin_amdgcn_ballot_w64(in[0]);
+    const int src = any ? __builtin_ctzll(any) : 0;
+    const size_t key = f0[0] + a[0];
+    const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)key, src), hi = (uint32_t)__shfl((int)(uint32_t)(key >> 32), src);
+    if (threadIdx.x == 0) {
+      s_hot = any ? ((size_t)hi << 32 | lo) : ~size_t(0);
+      s_sum = 0;
+    }
+  }
+  __syncthreads();
+  bool differs[FDF_PPT];
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) {
+    differs[k] = false;
+    if (in[k]) {
+      const size_t f = g[k] / P;
+      const int32_t bx = p.pos[2 * f], by = p.pos[2 * f + 1];
+      differs[k] = p.frames[g[k]] != p.bg[(size_t)(by + (int32_t)y[k]) * p.bw + (size_t)(bx + (int32_t)x[k])];
+    }
+  }
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) {
+    if (in[k]) {
+      p.label[g[k]] = a[k];  // (a pixel only ever shortens its own chain)
+      if (differs[k]) atomicOr(&p.area[f0[k] + a[k]], FDF_SEEDED);
+      if (a[k] == (uint32_t)(g[k] - f0[k])) {  // a root: its bounding box starts empty
+        p.minx[g[k]] = FDF_NONE;
+        p.maxx[g[k]] = 0;
+        p.miny[g[k]] = FDF_NONE;
+        p.maxy[g[k]] = 0;
+      }
+    }
+    // runs of equal roots along a row inside the wave: the run's first lane adds for all.  Only
+    // the area here — a frame's big background component takes thousands of these per frame on
+    // one address; its bounding box is never needed (fdf_keep adds boxes of kept components only)
+    uint32_t len;
+    if (fdf_run_head(a[k], x[k], len)) {
+      if (f0[k] + a[k] == s_hot)
+        atomicAdd(&s_sum, len);  // LDS
+      else
+        atomicAdd(&p.area[f0[k] + a[k]], len);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_sum) atomicAdd(&p.area[s_hot], s_sum);
 }
 
 __global__ __launch_bounds__(256) void fdf_keep(FdfParams p) {
   const uint32_t P = p.W * p.H;
-  const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-  const bool live = g < (size_t)p.n * P;
-  const uint32_t i = live ? (uint32_t)(g % P) : 0, x = i % p.W, y = i / p.W;
-  const size_t f0 = g - i;
-  const uint32_t root = live ? p.label[g] : FDF_NONE;
+  const size_t total = (size_t)p.n * P;
   const uint32_t limit = P / 5;  // fde.hpp:109-116
-  const bool keep = root != FDF_NONE && p.seeded[f0 + root] && p.area[f0 + root] <= limit;
-  if (keep && root == i) {
-    uint32_t* list = p.kept + (size_t)(g / P) * (p.kept_cap + 1);
-    const uint32_t at = atomicAdd(&list[0], 1u);
-    if (at < p.kept_cap)
-      list[1 + at] = i;
-    else
-      atomicOr(&p.status[3], 1u);
+  size_t g[FDF_PPT], f0[FDF_PPT];
+  uint32_t x[FDF_PPT], y[FDF_PPT], i[FDF_PPT], root[FDF_PPT];
+  bool live[FDF_PPT], keep[FDF_PPT];
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) {
+    g[k] = ((size_t)blockIdx.x * FDF_PPT + k) * 256 + threadIdx.x;
+    live[k] = g[k] < total;
+    i[k] = live[k] ? (uint32_t)(g[k] % P) : 0u;
+    x[k] = i[k] % p.W;
+    y[k] = i[k] / p.W;
+    f0[k] = g[k] - i[k];
+    root[k] = live[k] && fdf_interior(p, x[k], y[k]) ? p.label[g[k]] : FDF_NONE;  // (no labels outside the strips)
   }
-  uint32_t len;
-  if (fdf_run_head(keep ? root : FDF_NONE, x, len)) {  // bounding boxes of the kept components only
-    atomicMin(&p.minx[f0 + root], x);
-    atomicMax(&p.maxx[f0 + root], x + len - 1);
-    atomicMin(&p.miny[f0 + root], y);
-    atomicMax(&p.maxy[f0 + root], y);
+  uint32_t area[FDF_PPT];
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) area[k] = root[k] != FDF_NONE ? p.area[f0[k] + root[k]] : 0u;
+#pragma unroll
+  for (uint32_t k = 0; k < FDF_PPT; ++k) {
+    keep[k] = root[k] != FDF_NONE && (area[k] & FDF_SEEDED) && (area[k] & ~FDF_SEEDED) <= limit;
+    if (keep[k] && root[k] == i[k]) {
+      uint32_t* list = p.kept + (size_t)(g[k] / P) * (p.kept_cap + 1);
+      const uint32_t at = atomicAdd(&list[0], 1u);
+      if (at < p.kept_cap)
+        list[1 + at] = i[k];
+      else
+        atomicOr(&p.status[3], 1u);
+    }
+    uint32_t len;
+    if (fdf_run_head(keep[k] ? root[k] : FDF_NONE, x[k], len)) {  // bounding boxes of the kept components only
+      atomicMin(&p.minx[f0[k] + root[k]], x[k]);
+      atomicMax(&p.maxx[f0[k] + root[k]], x[k] + len - 1);
+      atomicMin(&p.miny[f0[k] + root[k]], y[k]);
+      atomicMax(&p.maxy[f0[k] + root[k]], y[k]);
+    }
+    if (live[k]) p.mask[g[k]] = keep[k] ? 1 : 0;
   }
-  if (live) p.mask[g] = keep ? 1 : 0;
 }
 
 // one workgroup per frame, its four waves take the kept components in turn
