@@ -171,19 +171,20 @@ __global__ __launch_bounds__(256) void fdf_stitch(FdfParams p, uint32_t R, uint3
 constexpr uint32_t FDF_PPT = 4;
 
 __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
-  const uint32_t P = p.W * p.H;
-  const size_t total = (size_t)p.n * P;
+  // grid: x = frame, y = chunk of 256 * FDF_PPT pixels of it (no 64-bit divisions per pixel)
+  const uint32_t P = p.W * p.H, f = blockIdx.x;
+  const size_t fbase = (size_t)f * P;
   size_t g[FDF_PPT], f0[FDF_PPT];
   uint32_t x[FDF_PPT], y[FDF_PPT], a[FDF_PPT];
   bool in[FDF_PPT];
 #pragma unroll
   for (uint32_t k = 0; k < FDF_PPT; ++k) {
-    g[k] = ((size_t)blockIdx.x * FDF_PPT + k) * 256 + threadIdx.x;
-    const bool live = g[k] < total;
-    const uint32_t i = live ? (uint32_t)(g[k] % P) : 0u;
-    x[k] = i % p.W;
+    const uint32_t i = (blockIdx.y * FDF_PPT + k) * 256 + threadIdx.x;
+    const bool live = i < P;
+    g[k] = fbase + i;
     y[k] = i / p.W;
-    f0[k] = g[k] - i;
+    x[k] = i - y[k] * p.W;
+    f0[k] = fbase;
     in[k] = live && fdf_interior(p, x[k], y[k]);
     a[k] = in[k] ? i : FDF_NONE;
   }
@@ -215,13 +216,12 @@ __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
     }
   }
   __syncthreads();
+  const int32_t bx = p.pos[2 * f], by = p.pos[2 * f + 1];
   bool differs[FDF_PPT];
 #pragma unroll
   for (uint32_t k = 0; k < FDF_PPT; ++k) {
     differs[k] = false;
     if (in[k]) {
-      const size_t f = g[k] / P;
-      const int32_t bx = p.pos[2 * f], by = p.pos[2 * f + 1];
       differs[k] = p.frames[g[k]] != p.bg[(size_t)(by + (int32_t)y[k]) * p.bw + (size_t)(bx + (int32_t)x[k])];
     }
   }
@@ -253,20 +253,20 @@ __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
 }
 
 __global__ __launch_bounds__(256) void fdf_keep(FdfParams p) {
-  const uint32_t P = p.W * p.H;
-  const size_t total = (size_t)p.n * P;
+  const uint32_t P = p.W * p.H, f = blockIdx.x;  // grid as fdf_stats
+  const size_t fbase = (size_t)f * P;
   const uint32_t limit = P / 5;  // fde.hpp:109-116
   size_t g[FDF_PPT], f0[FDF_PPT];
   uint32_t x[FDF_PPT], y[FDF_PPT], i[FDF_PPT], root[FDF_PPT];
   bool live[FDF_PPT], keep[FDF_PPT];
 #pragma unroll
   for (uint32_t k = 0; k < FDF_PPT; ++k) {
-    g[k] = ((size_t)blockIdx.x * FDF_PPT + k) * 256 + threadIdx.x;
-    live[k] = g[k] < total;
-    i[k] = live[k] ? (uint32_t)(g[k] % P) : 0u;
-    x[k] = i[k] % p.W;
+    i[k] = (blockIdx.y * FDF_PPT + k) * 256 + threadIdx.x;
+    live[k] = i[k] < P;
+    g[k] = fbase + i[k];
     y[k] = i[k] / p.W;
-    f0[k] = g[k] - i[k];
+    x[k] = i[k] - y[k] * p.W;
+    f0[k] = fbase;
     root[k] = live[k] && fdf_interior(p, x[k], y[k]) ? p.label[g[k]] : FDF_NONE;  // (no labels outside the strips)
   }
   uint32_t area[FDF_PPT];
@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void fdf_keep(FdfParams p) {
   for (uint32_t k = 0; k < FDF_PPT; ++k) {
     keep[k] = root[k] != FDF_NONE && (area[k] & FDF_SEEDED) && (area[k] & ~FDF_SEEDED) <= limit;
     if (keep[k] && root[k] == i[k]) {
-      uint32_t* list = p.kept + (size_t)(g[k] / P) * (p.kept_cap + 1);
+      uint32_t* list = p.kept + (size_t)f * (p.kept_cap + 1);
       const uint32_t at = atomicAdd(&list[0], 1u);
       if (at < p.kept_cap)
         list[1 + at] = i[k];
@@ -294,8 +294,9 @@ __global__ __launch_bounds__(256) void fdf_keep(FdfParams p) {
   }
 }
 
-// one workgroup per frame, its four waves take the kept components in turn
-__global__ __launch_bounds__(256) void fdf_boxes(FdfParams p) {
+// one workgroup per frame, its sixteen waves take the kept components in turn (four waves: 160 us
+// per 833 frames with ~230 kept components each — three waves per SIMD, every one a serial loop)
+__global__ __launch_bounds__(1024) void fdf_boxes(FdfParams p) {
   const uint32_t f = blockIdx.x, lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
   const uint32_t* list = p.kept + (size_t)f * (p.kept_cap + 1);
   const uint32_t cnt = min(list[0], p.kept_cap);
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void fdf_boxes(FdfParams p) {
   const size_t f0 = (size_t)f * P;
   const uint32_t* L = p.label + f0;
   uint8_t* m = p.mask + f0;
-  for (uint32_t slot = wave; slot < cnt; slot += 4) {
+  for (uint32_t slot = wave; slot < cnt; slot += blockDim.x >> 6) {
     const uint32_t root = list[1 + slot];
     const uint32_t x0 = p.minx[f0 + root], x1 = p.maxx[f0 + root], y0 = p.miny[f0 + root], y1 = p.maxy[f0 + root];
     // cdt::limits fed with the x of the left/right edge pixels in row-major order
