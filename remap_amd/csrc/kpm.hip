@@ -319,11 +319,18 @@ struct KpmBuildParams {
 };
 
 __device__ __forceinline__ void load_code(const rmx_desc* d, uint32_t c[4]) {
-  const uint16_t* s = reinterpret_cast<const uint16_t*>(d);  // 18-byte rows, 2-byte aligned
-  c[0] = s[0] | (uint32_t)s[1] << 16;
-  c[1] = s[2] | (uint32_t)s[3] << 16;
-  c[2] = s[4] | (uint32_t)s[5] << 16;
-  c[3] = s[6] & 0xffu;
+  uint4 v;  // 18-byte rows, 2-byte aligned: ONE unaligned 16-byte load (seven 2-byte loads otherwise)
+  __builtin_memcpy(&v, d, 16);
+  c[0] = v.x;
+  c[1] = v.y;
+  c[2] = v.z;
+  c[3] = v.w & 0xffu;
+}
+// x | y << 16 of a row: one unaligned 4-byte load
+__device__ __forceinline__ uint32_t load_xy(const rmx_desc* d) {
+  uint32_t v;
+  __builtin_memcpy(&v, reinterpret_cast<const uint8_t*>(d) + 14, 4);
+  return v;
 }
 __device__ __forceinline__ bool same_code(const uint32_t a[4], const uint32_t b[4]) {
   return a[0] == b[0] && a[1] == b[1] && a[2] == b[2] && a[3] == b[3];
@@ -471,7 +478,7 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
     for (uint32_t j = j0; j < j1; ++j) {
       uint32_t first = keys[j] >> 16, i = keys[j] & 0xffffu;
       const rmx_desc* d = desc + ent[i];
-      pts[p_off + j] = (uint32_t)d->x | (uint32_t)d->y << 16;
+      pts[p_off + j] = load_xy(d);
       if (j == 0 || first != (keys[j - 1] >> 16)) {
         gstart[g_off + r + gid] = p_off + j;
         gfirst[g_off + gid] = ent[first];
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   uint32_t* ght = pool + kpm_off_ht(p.kmax);
   if (lane < e) {
     const rmx_desc* d = desc + ent[r][key & 0xffffu];
-    pts[p_off + lane] = (uint32_t)d->x | (uint32_t)d->y << 16;
+    pts[p_off + lane] = load_xy(d);
     if (start) {
       gstart[g_off + r + gid] = p_off + lane;
       gfirst[g_off + gid] = ent[r][first];
@@ -833,7 +840,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   for (uint32_t j = lane; j < e; j += 64) {
     const uint32_t first = keys[r][j] >> 16, i = keys[r][j] & 0xffffu;
     const rmx_desc* d = desc + ent[r][i];
-    pts[p_off + j] = (uint32_t)d->x | (uint32_t)d->y << 16;
+    pts[p_off + j] = load_xy(d);
     if (j == 0 || first != (keys[r][j - 1] >> 16)) {
       const uint32_t gid = gid_of[r][first];
       gstart[g_off + r + gid] = p_off + j;

@@ -48,16 +48,12 @@ __device__ inline void bitonic_sort_u64(uint64_t* a, uint32_t n2) {
 __device__ __forceinline__ void write_row(const TableParams& p, rmx_desc* out, uint32_t i, const RawDesc& r) {
   uint32_t x = r.xy & 0xffffu, y = r.xy >> 16;
   uint32_t m = region_mask(p.bands, x, y);
-  uint16_t* o = reinterpret_cast<uint16_t*>(out + i);
-  o[0] = (uint16_t)r.code[0];
-  o[1] = (uint16_t)(r.code[0] >> 16);
-  o[2] = (uint16_t)r.code[1];
-  o[3] = (uint16_t)(r.code[1] >> 16);
-  o[4] = (uint16_t)r.code[2];
-  o[5] = (uint16_t)(r.code[2] >> 16);
-  o[6] = (uint16_t)((r.code[3] & 0xffu) | m << 8);
-  o[7] = (uint16_t)x;
-  o[8] = (uint16_t)y;
+  // 18-byte rows, 2-byte aligned: one unaligned 16-byte store and a 2-byte one (nine 2-byte stores otherwise)
+  const uint4 v = make_uint4(r.code[0], r.code[1], r.code[2], (r.code[3] & 0xffu) | m << 8 | x << 16);
+  const uint16_t yy = (uint16_t)y;
+  uint8_t* o = reinterpret_cast<uint8_t*>(out + i);
+  __builtin_memcpy(o, &v, 16);
+  __builtin_memcpy(o + 16, &yy, 2);
 }
 
 // Three ways to the same table.
