@@ -76,9 +76,30 @@ __device__ __forceinline__ void kpe_table_block(const TableParams& p, uint64_t* 
   if (k > 128 && p.rank_words) {
     uint32_t* bm = reinterpret_cast<uint32_t*>(keys);
     const uint32_t nb = p.rank_words, cw = (nb + 255) / 256;
-    for (uint32_t w = threadIdx.x; w < nb; w += 256) bm[w] = 0;
+    // the first RPT * 256 records stay in registers from here to their rows (all their loads in
+    // flight together; one 4-byte and one 32-byte load per record in two loops otherwise)
+    constexpr uint32_t RPT = 5;
+    uint4 code[RPT];
+    uint32_t xyr[RPT];
+#pragma unroll
+    for (uint32_t u = 0; u < RPT; ++u) {
+      const uint32_t i = threadIdx.x + 256 * u;
+      code[u] = make_uint4(0, 0, 0, 0);
+      xyr[u] = 0;
+      if (i < k) {
+        code[u] = *reinterpret_cast<const uint4*>(raw[i].code);
+        xyr[u] = raw[i].xy;
+      }
+    }
+    for (uint32_t w = threadIdx.x; w < nb; w += 256) bm[w] = 0;  // (under the loads)
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < k; i += 256) {
+#pragma unroll
+    for (uint32_t u = 0; u < RPT; ++u)
+      if (threadIdx.x + 256 * u < k) {
+        const uint32_t b = (xyr[u] & 0xffffu) * p.H + (xyr[u] >> 16);
+        atomicOr(&bm[b >> 5], 1u << (b & 31u));
+      }
+    for (uint32_t i = threadIdx.x + 256 * RPT; i < k; i += 256) {
       const uint32_t xy = raw[i].xy, b = (xy & 0xffffu) * p.H + (xy >> 16);
       atomicOr(&bm[b >> 5], 1u << (b & 31u));
     }
@@ -100,12 +121,26 @@ __device__ __forceinline__ void kpe_table_block(const TableParams& p, uint64_t* 
     for (uint32_t w = 0; w < wave; ++w) base += wave_tot[w];
     chunk_pre[threadIdx.x] = base + incl - cnt;
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < k; i += 256) {
-      const RawDesc& r = raw[i];
-      const uint32_t b = (r.xy & 0xffffu) * p.H + (r.xy >> 16), w = b >> 5, c = w / cw;
+    auto rank_of = [&](uint32_t xy) {
+      const uint32_t b = (xy & 0xffffu) * p.H + (xy >> 16), w = b >> 5, c = w / cw;
       uint32_t rank = chunk_pre[c] + __popc(bm[w] & ((1u << (b & 31u)) - 1u));
       for (uint32_t v = c * cw; v < w; ++v) rank += __popc(bm[v]);
-      write_row(p, out, rank, r);
+      return rank;
+    };
+#pragma unroll
+    for (uint32_t u = 0; u < RPT; ++u)
+      if (threadIdx.x + 256 * u < k) {
+        RawDesc r;
+        r.code[0] = code[u].x;
+        r.code[1] = code[u].y;
+        r.code[2] = code[u].z;
+        r.code[3] = code[u].w;
+        r.xy = xyr[u];
+        write_row(p, out, rank_of(xyr[u]), r);
+      }
+    for (uint32_t i = threadIdx.x + 256 * RPT; i < k; i += 256) {
+      const RawDesc& r = raw[i];
+      write_row(p, out, rank_of(r.xy), r);
     }
     __syncthreads();  // LDS is reused by the workgroup's next frame
     return;
