@@ -113,29 +113,58 @@ __device__ __forceinline__ void wave_sort_inlane(uint32_t (&key)[KPL], uint32_t 
       key[s | JS] = up ? hi : lo;
     }
 }
-template <uint32_t KPL>
-__device__ __forceinline__ void wave_sort(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
-  static_assert(KPL == 4 || KPL == 8, "wave_sort: 4 or 8 keys per lane");
-  for (uint32_t k = 2; k <= n2; k <<= 1)
-    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-      if (j < 64) {
-        const bool lower = (lane & j) == 0;
-#pragma unroll
-        for (uint32_t s = 0; s < KPL; ++s)
-          if (s * 64 < n2) {
-            const uint32_t other = (uint32_t)__shfl_xor((int)key[s], (int)j);
-            const bool up = ((s * 64 + lane) & k) == 0;
-            key[s] = (lower == up) ? min(key[s], other) : max(key[s], other);
-          }
-      } else if (j == 64) {
-        wave_sort_inlane<KPL, 1>(key, n2, k);
-      } else if (j == 128) {
-        wave_sort_inlane<KPL, 2>(key, n2, k);
-      } else {
-        wave_sort_inlane<KPL, 4>(key, n2, k);
-      }
-    }
+// Value of lane (lane ^ J): DPP where the pattern exists (quad_perm for 1 and 2, row_ror:8 = xor 8
+// inside a row of 16), ds_swizzle for 4 and 16, ds_bpermute for 32.  All lanes must be active.
+template <uint32_t J>
+__device__ __forceinline__ uint32_t lane_xor(uint32_t v, uint32_t lane) {
+  if constexpr (J == 1)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, false);  // quad_perm:[1,0,3,2]
+  else if constexpr (J == 2)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, false);  // quad_perm:[2,3,0,1]
+  else if constexpr (J == 4)
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x101f);  // bit mode: and 0x1f, xor 4
+  else if constexpr (J == 8)
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xf, 0xf, false);  // row_ror:8
+  else if constexpr (J == 16)
+    return (uint32_t)__builtin_amdgcn_ds_swizzle((int)v, 0x401f);  // bit mode: and 0x1f, xor 16
+  else
+    return (uint32_t)__builtin_amdgcn_ds_bpermute((int)((lane ^ 32u) << 2), (int)v);
 }
 
+// The network is unrolled at compile time (stage K, distance J): the exchange pattern and the
+// min/max choice are constants of the step — 3-4 instructions per key and step against ~9 with
+// run-time distances through ds_bpermute.  Stages beyond n2 are skipped (uniform).
+template <uint32_t KPL, uint32_t K, uint32_t J>
+__device__ __forceinline__ void wave_sort_step(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
+  if constexpr (J >= 64) {
+    wave_sort_inlane<KPL, J / 64>(key, n2, K);
+  } else {
+    const bool lower = (lane & J) == 0;
+#pragma unroll
+    for (uint32_t s = 0; s < KPL; ++s)
+      if (s * 64 < n2) {
+        const uint32_t other = lane_xor<J>(key[s], lane);
+        const bool up = K < 64 ? (lane & K) == 0 : ((s * 64) & K) == 0;
+        key[s] = (lower == up) ? min(key[s], other) : max(key[s], other);
+      }
+  }
+  if constexpr (J > 1) wave_sort_step<KPL, K, J / 2>(key, n2, lane);
+}
+template <uint32_t KPL, uint32_t K>
+__device__ __forceinline__ void wave_sort_stage(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
+  if (K <= n2) wave_sort_step<KPL, K, K / 2>(key, n2, lane);
+  if constexpr (K < 64 * KPL) wave_sort_stage<KPL, 2 * K>(key, n2, lane);
+}
+template <uint32_t KPL>
+__device__ __forceinline__ void wave_sort(uint32_t (&key)[KPL], uint32_t n2, uint32_t lane) {
+  static_assert(KPL == 1 || KPL == 2 || KPL == 4 || KPL == 8, "wave_sort: 1, 2, 4 or 8 keys per lane");
+  wave_sort_stage<KPL, 2>(key, n2, lane);
+}
+// one key per lane
+__device__ __forceinline__ uint32_t wave_sort1(uint32_t key, uint32_t n2, uint32_t lane) {
+  uint32_t k1[1] = {key};
+  wave_sort<1>(k1, n2, lane);
+  return k1[0];
+}
 
 }  // namespace rmx

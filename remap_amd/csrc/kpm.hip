@@ -174,16 +174,7 @@ __device__ __forceinline__ void umap_level_regs(const uint64_t* h, int level, ui
     const uint32_t t = sl * 64 + lane;
     key[sl] = t < mk ? (0xffffu - bmin[bkt[sl]]) << 16 | (0xffffu - t) : 0xffffffffu;
   }
-  if constexpr (KPL == 1) {
-    for (uint32_t k = 2; k <= n2; k <<= 1)
-      for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-        const uint32_t other = (uint32_t)__shfl_xor((int)key[0], (int)j);
-        const bool up = (lane & k) == 0, lower = (lane & j) == 0;
-        key[0] = (lower == up) ? min(key[0], other) : max(key[0], other);
-      }
-  } else {
-    wave_sort<KPL>(key, n2, lane);
-  }
+  wave_sort<KPL>(key, n2, lane);
 #pragma unroll
   for (uint32_t sl = 0; sl < KPL; ++sl) {
     const uint32_t j = sl * 64 + lane;
@@ -604,25 +595,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     // 3. order entries by (first occurrence of their code, scan order): bitonic sort of one key per lane
     if (lane < e) key = htl[r][myslot] << 16 | lane;
     // (unused lanes hold 0xffffffff; a region of the sparse stream has ~10 entries: 16 lanes, 10 steps)
-    if (e <= 16) {
-#pragma unroll
-      for (uint32_t kk = 2; kk <= 16; kk <<= 1)
-#pragma unroll
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
-          bool up = (lane & kk) == 0, lower = (lane & j) == 0;
-          key = (lower == up) ? min(key, other) : max(key, other);
-        }
-    } else {
-#pragma unroll
-      for (uint32_t kk = 2; kk <= 64; kk <<= 1)
-#pragma unroll
-        for (uint32_t j = kk >> 1; j > 0; j >>= 1) {
-          uint32_t other = (uint32_t)__shfl_xor((int)key, (int)j);
-          bool up = (lane & kk) == 0, lower = (lane & j) == 0;
-          key = (lower == up) ? min(key, other) : max(key, other);
-        }
-    }
+    key = wave_sort1(key, e <= 16 ? 16u : 64u, lane);
     // 4. groups in first-occurrence order
     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
     start = lane < e && (lane == 0 || (key >> 16) != (prev >> 16));
