@@ -516,49 +516,108 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
 // bitonic sort in registers, one lane replaying libstdc++'s node order), two block barriers
 // to exchange the regions' sizes.  It runs before kpm_build<2048,...>, which then takes
 // only the frames marked in `needs_large`.
-constexpr uint32_t KS_RC = 64;  // entries per region
+// The kernel is VALU-issue-bound (~650 wave-instructions per region, 52 M per 10 000 sparse
+// frames = the 94 us it took with a wave per region), and a sparse region fills 10 of its 64
+// lanes: the first pass gives a region HALF a wave (LPR = 32 lanes, two regions per wave), frames
+// with a region of 33-64 entries go on to the wave-per-region instance (LPR = 64, tier 4).
 
-__global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_t* needs_large, uint32_t* work, uint32_t work_stride) {
-  if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the matcher's work lists (used by later launches)
-    work[0] = 0;
-    work[work_stride] = 0;
-    work[2 * work_stride] = 0;
+// Iteration order of a code map of n <= 32 groups, for the two 32-lane halves of a wave side by
+// side (the halves differ in n: control flow stays wave-uniform, finished halves idle).  Same
+// levels, keys and result as umap_order_par.
+template <typename OutT>
+__device__ __forceinline__ void umap_order_half(const uint64_t* h, uint32_t n, uint16_t* seq_a, uint16_t* seq_b, uint32_t* bmin,
+                                                OutT* order, uint32_t l) {
+  const WaveBarrier bar{};
+  uint16_t* cur = seq_a;
+  uint16_t* nxt = seq_b;
+  uint32_t nk = 0;
+#pragma unroll
+  for (int level = 0; level < 3; ++level) {
+    const uint32_t B = level == 0 ? 13u : level == 1 ? 29u : 59u, mk = min(B, n);
+    const bool on = level == 0 || nk < n;
+    if (__builtin_amdgcn_ballot_w64(on) == 0) break;  // uniform
+    if (on)
+      for (uint32_t b = l; b < B; b += 32) bmin[b] = 0xffffffffu;
+    bar();
+    uint32_t bkt = 0;
+    const bool live = on && l < mk;
+    if (live) {
+      const uint32_t e = l < nk ? cur[l] : l;
+      bkt = umap_bucket(h[e], level);
+      atomicMin(&bmin[bkt], l);
+    }
+    bar();
+    uint32_t key = live ? (0xffffu - bmin[bkt]) << 16 | (0xffffu - l) : 0xffffffffu;
+    key = wave_sort1(key, level == 0 ? 16u : 32u, l);
+    if (live) {
+      const uint32_t t = 0xffffu - (key & 0xffffu);
+      nxt[l] = (uint16_t)(t < nk ? cur[t] : t);
+    }
+    bar();
+    if (on) {
+      uint16_t* sw = cur;
+      cur = nxt;
+      nxt = sw;
+      nk = mk;
+    }
   }
+  if (l < n) order[l] = (OutT)cur[l];
+}
+
+// LPR lanes per region; FIRST: the pass over every frame (writes every tier word), else the
+// frames of tier 4.  Returns through the tier word: 0 built, 1 / 3 / 4 = the instance to go to.
+template <uint32_t LPR, bool FIRST>
+__device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, uint32_t* needs_large, uint32_t fslot) {
+  static_assert(LPR == 32 || LPR == 64, "half a wave or a wave per region");
+  constexpr uint32_t KS_RC = LPR;                     // entries per region
+  constexpr uint32_t KS_BK = LPR == 64 ? 127u : 59u;  // buckets of the last level a map of KS_RC groups reaches
   __shared__ uint16_t ent[8][KS_RC];
   __shared__ uint32_t htl[8][2 * KS_RC];
   __shared__ uint64_t hg[8][KS_RC];
   __shared__ uint16_t seq_a[8][KS_RC], seq_b[8][KS_RC], gid_of[8][KS_RC];
-  __shared__ uint32_t okeys[8][KS_RC], bmin[8][127];
+  __shared__ uint32_t okeys[8][KS_RC], bmin[8][KS_BK];
   __shared__ uint32_t s_e[8], s_g[8];
-  __shared__ uint32_t s_big;
+  __shared__ uint32_t s_big, s_maxe;
 
-  const uint32_t fslot = blockIdx.x;
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t lane = threadIdx.x & (LPR - 1u);  // lane inside the region's group
+  const uint32_t r = LPR == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x / LPR;
+  const uint32_t gshift = LPR == 64 ? 0u : (threadIdx.x & 32u);  // my group's bits inside a wave ballot
+  auto gballot = [&](bool pred) -> uint64_t {
+    const uint64_t b = __builtin_amdgcn_ballot_w64(pred);
+    return LPR == 64 ? b : (b >> gshift) & 0xffffffffull;
+  };
+  auto gcount_below = [&](uint64_t m) -> uint32_t { return (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull)); };
   const uint32_t EMPTY = 0xffffffffu;
-  if (threadIdx.x == 0) s_big = k > 256 ? 1u : 0u;
+  if (threadIdx.x == 0) {
+    s_big = k > 256 ? 1u : 0u;
+    s_maxe = 0;
+  }
   __syncthreads();
   const bool mine = r < p.nreg && k <= 256;
   // 1. region entries in scan order
   uint32_t e = 0;
-  if (mine) {
-    for (uint32_t base = 0; base < k; base += 64) {
+  if (k <= 256) {  // (uniform; every lane takes part in the ballots)
+    for (uint32_t base = 0; base < k; base += LPR) {
       uint32_t i = base + lane;
-      bool in = i < k && ((desc[i].region_mask >> r) & 1u);
-      uint64_t bal = __builtin_amdgcn_ballot_w64(in);
-      uint32_t pos = e + mbcnt(bal);
+      bool in = mine && i < k && ((desc[i].region_mask >> r) & 1u);
+      uint64_t bal = gballot(in);
+      uint32_t pos = e + gcount_below(bal);
       if (in && pos < KS_RC) ent[r][pos] = (uint16_t)i;
       e += (uint32_t)__builtin_popcountll(bal);
     }
-    if (e > KS_RC && lane == 0) atomicOr(&s_big, 1u);
+    if (e > KS_RC && lane == 0) {
+      atomicOr(&s_big, 1u);
+      atomicMax(&s_maxe, e);
+    }
   }
   __syncthreads();
   if (s_big) {  // uniform for the block
-    if (threadIdx.x == 0) needs_large[fslot] = k > 4096 ? 3u : 1u;  // tier: wave-per-region instances (1, 2) or general (3)
+    // tier: wave-per-region instances (4: <= 64 entries per region, 1, 2) or general (3)
+    if (threadIdx.x == 0) needs_large[fslot] = k > 4096 ? 3u : (LPR == 32 && k <= 256 && s_maxe <= 64) ? 4u : 1u;
     return;
   }
   if (threadIdx.x == 0) needs_large[fslot] = 0u;
@@ -566,13 +625,14 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   uint32_t c[4] = {0, 0, 0, 0}, myslot = 0, w2 = 0, w1 = 0, slots = 16, G = 0, gid = 0, first = 0;
   bool start = false;
   uint32_t key = 0xffffffffu;
-  if (mine) {
+  {
     while (slots < 2 * e) slots <<= 1;
     const uint32_t mask = slots - 1;
-    for (uint32_t s = lane; s < slots; s += 64) htl[r][s] = EMPTY;
+    if (mine)
+      for (uint32_t s = lane; s < slots; s += LPR) htl[r][s] = EMPTY;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane < e) {
+    if (mine && lane < e) {
       load_code(desc + ent[r][lane], c);
       uint32_t s = fnv_code_lo(c) & mask;
       for (;;) {
@@ -588,31 +648,29 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
       }
       myslot = s;
     }
-    w2 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < e && (c[3] & 0xfu) == 2u));
-    w1 = (uint32_t)__builtin_popcountll(__builtin_amdgcn_ballot_w64(lane < e && (c[3] & 0xfu) == 1u));
+    w2 = (uint32_t)__builtin_popcountll(gballot(mine && lane < e && (c[3] & 0xfu) == 2u));
+    w1 = (uint32_t)__builtin_popcountll(gballot(mine && lane < e && (c[3] & 0xfu) == 1u));
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
     // 3. order entries by (first occurrence of their code, scan order): bitonic sort of one key per lane
-    if (lane < e) key = htl[r][myslot] << 16 | lane;
-    // (unused lanes hold 0xffffffff; a region of the sparse stream has ~10 entries: 16 lanes, 10 steps)
-    key = wave_sort1(key, e <= 16 ? 16u : 64u, lane);
+    if (mine && lane < e) key = htl[r][myslot] << 16 | lane;
+    // (unused lanes hold 0xffffffff; a region of the sparse stream has ~10 entries: 16 lanes, 10 steps;
+    // the size is the wave's: both halves run the same network)
+    const uint32_t n2 = __builtin_amdgcn_ballot_w64(e > 16) == 0 ? 16u : LPR;
+    key = wave_sort1(key, n2, lane);
     // 4. groups in first-occurrence order
     const uint32_t prev = (uint32_t)__shfl_up((int)key, 1);
-    start = lane < e && (lane == 0 || (key >> 16) != (prev >> 16));
-    const uint64_t sb = __builtin_amdgcn_ballot_w64(start);
+    start = mine && lane < e && (lane == 0 || (key >> 16) != (prev >> 16));
+    const uint64_t sb = gballot(start);
     G = (uint32_t)__builtin_popcountll(sb);
-    gid = mbcnt(sb);  // group id of a start lane
+    gid = gcount_below(sb);  // group id of a start lane
     first = key >> 16;
-    if (lane == 0) {
-      s_e[r] = e;
-      s_g[r] = G;
+    if (lane == 0 && r < 8) {
+      s_e[r] = mine ? e : 0u;
+      s_g[r] = mine ? G : 0u;
     }
-  } else if (lane == 0 && r < 8) {
-    s_e[r] = 0;
-    s_g[r] = 0;
   }
   __syncthreads();
-  if (!mine) return;
   // pool offsets: exclusive sums over the regions before this one
   uint32_t p_off = 0, g_off = 0, ht_off = 0;
   for (uint32_t q = 0; q < r; ++q) {
@@ -627,7 +685,7 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   uint32_t* gstart = pool + kpm_off_gstart(p.kmax);
   uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
   uint32_t* ght = pool + kpm_off_ht(p.kmax);
-  if (lane < e) {
+  if (mine && lane < e) {
     const rmx_desc* d = desc + ent[r][key & 0xffffu];
     pts[p_off + lane] = load_xy(d);
     if (start) {
@@ -643,11 +701,12 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
   // export the code index: slot -> group id + 1
-  for (uint32_t sidx = lane; sidx < slots; sidx += 64) {
-    uint32_t v = htl[r][sidx];
-    ght[ht_off + sidx] = v == EMPTY ? 0u : (uint32_t)gid_of[r][v] + 1u;
-  }
-  if (lane == 0) {
+  if (mine)
+    for (uint32_t sidx = lane; sidx < slots; sidx += LPR) {
+      uint32_t v = htl[r][sidx];
+      ght[ht_off + sidx] = v == EMPTY ? 0u : (uint32_t)gid_of[r][v] + 1u;
+    }
+  if (mine && lane == 0) {
     gstart[g_off + r + G] = p_off + e;
     uint32_t* h = pool + r * 8;
     h[H_E] = e;
@@ -660,8 +719,23 @@ __global__ __launch_bounds__(512) void kpm_build_small(KpmBuildParams p, uint32_
     h[H_W1] = w1;
   }
   // iteration order of this region's code map, wave-parallel
-  umap_order_par<64, 64>(hg[r], G, okeys[r], seq_a[r], seq_b[r], bmin[r], WaveBarrier{},
-                     pool + kpm_off_giter(p.kmax) + g_off, lane);
+  if constexpr (LPR == 64) {
+    if (!mine) return;  // (wave-uniform)
+    umap_order_par<64, 64>(hg[r], G, okeys[r], seq_a[r], seq_b[r], bmin[r], WaveBarrier{},
+                           pool + kpm_off_giter(p.kmax) + g_off, lane);
+  } else {
+    umap_order_half(hg[r & 7u], mine ? G : 0u, seq_a[r & 7u], seq_b[r & 7u], bmin[r & 7u], pool + kpm_off_giter(p.kmax) + g_off, lane);
+  }
+}
+
+// first pass, every frame: half a wave per region
+__global__ __launch_bounds__(256) void kpm_build_small(KpmBuildParams p, uint32_t* needs_large, uint32_t* work, uint32_t work_stride) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {  // counters of the matcher's work lists (used by later launches)
+    work[0] = 0;
+    work[work_stride] = 0;
+    work[2 * work_stride] = 0;
+  }
+  kpm_build_small_frame<32, true>(p, needs_large, blockIdx.x);
 }
 
 // ---- medium frames: one wave per region, up to 256 entries per region ---------------------------------
@@ -873,6 +947,10 @@ __device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want
 template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
 __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large, uint32_t nslots) {
   kpm_for_tier(needs_large, 3u, nslots, [&](uint32_t fslot) { kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot); });
+}
+// tier 4: a wave per region, up to 64 entries per region
+__global__ __launch_bounds__(512) void kpm_build_small64(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
+  kpm_for_tier(tier, 4u, nslots, [&](uint32_t fslot) { kpm_build_small_frame<64, false>(p, tier, fslot); });
 }
 template <uint32_t RC, uint32_t TIN>
 __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {

@@ -161,3 +161,15 @@ def test_kpm_large_tables_kmax_8192(gpu):
     frames = np.stack([np.ascontiguousarray(base[:, x:x + 320]) for x in (0, 2, 5, 5, 9)])
     g, _ = check_seq(frames, kmax=8192)
     assert max(len(t) for t in g["tabs"]) > 2048
+
+
+@pytest.mark.parametrize("dens", [150, 120, 90, 70, 55])
+def test_kpm_build_tiers_between_sparse_and_dense(gpu, dens):
+    """Densities at which regions hold 10-30, 17-32, 33-64 and 65-256 entries: the half-wave
+    first pass, its 32-key sorts, the wave-per-region instance (tier 4) and the first medium
+    instance all build tables the matcher reads bit-for-bit like the oracle."""
+    frames, _ = scroller_v1(14, dens=dens)
+    g, _ = check_seq(frames)
+    per_region = [np.bincount(np.concatenate([np.flatnonzero([(m >> r) & 1 for m in t["region_mask"]]) * 0 + r for r in range(8)]),
+                              minlength=8).max() for t in g["tabs"]]
+    assert max(per_region) > 16  # beyond the 16-key network
