@@ -44,19 +44,22 @@ def cpu_baseline(frames_host):
     import orclib as O  # oracle/: allowed here only as the reported CPU baseline
 
     n = len(frames_host)
+    def timed(fn):  # passes over the sample until ~10 s of CPU work are on the clock (at most 4)
+        t0, passes = time.perf_counter(), 0
+        while passes < 4 and (passes == 0 or time.perf_counter() - t0 < 10.0):
+            fn(frames_host)
+            passes += 1
+        return time.perf_counter() - t0, passes
+
     if O.ref_full() is not None:
-        t0 = time.perf_counter()
-        O.ref_frc(frames_host)
-        dt = time.perf_counter() - t0
-        return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
+        dt, passes = timed(O.ref_frc)
+        return {"value": n * passes / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
                 "sample": f"reference frc::collector::collect (kpe+kpm+fgm blit, no-op codec, g++ -O2 -mavx2) "
-                          f"on the first {n} frames of the same stream, {dt:.1f} s"}
-    t0 = time.perf_counter()
-    O.orc_frc(frames_host)
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
+                          f"on the first {n} frames of the same stream, {passes} passes, {dt:.1f} s"}
+    dt, passes = timed(O.orc_frc)
+    return {"value": n * passes / dt, "unit": "frames/s", "cores": 1, "kind": "port",
             "sample": f"oracle/remap_oracle.cpp kpe+kpm+frc loop on the first {n} frames of the same stream, "
-                      f"{dt:.1f} s"}
+                      f"{passes} passes, {dt:.1f} s"}
 
 
 VALU_RATE_PER_NS = 558.0  # wave-instructions per ns, whole chip: v_min3/med3/max3_u32 streams, tools/micro/valu_rate.hip
