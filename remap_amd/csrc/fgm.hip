@@ -220,11 +220,15 @@ __device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
   return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
 }
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t blit_rsrc(const uint8_t* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), (short)0, (int)bytes, 0x00020000);
+}
+
 __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   // bins[k][slot]: dword k (bins 2k, 2k+1) of the pixel in `slot`; a thread's pixel j sits in
   // slot row*128 + j*32 + (tid & 31), so for any k the 32 lanes of a half-wave hit 32
   // different banks whatever colours they carry (a [pixel][8] layout is a 32-way conflict)
-  __shared__ uint32_t bins[8][BL_TW * BL_TH];  // 32 KB
+  __shared__ uint32_t bins[9][BL_TW * BL_TH];  // 32 KB + a ninth row nobody reads: pixels outside a frame or masked out land there
   __shared__ uint32_t list[256];
   __shared__ int list_ax[256], list_ay[256];  // canvas origin of the listed frames
   __shared__ uint32_t nlist;
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) bins[k][slot0 + (uint32_t)j * 32] = 0;
   const int W = (int)p.W, H = (int)p.H;
+  const int YW = Y * W;
   const uint32_t tcol = blockIdx.x % p.tiles_x;
   const uint32_t lbeg = p.col_cnt[tcol], lend = p.col_cnt[tcol + 1];  // this tile column's frames
   for (uint32_t base = lbeg; base < lend; base += 256) {
@@ -269,19 +274,20 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       raw = 0;
       mraw = 0;
       sh = 8;
-      if (i >= m) return;
-      // the frame and its canvas origin are the same for the whole workgroup: scalar registers,
-      // scalar arithmetic for the frame's base address
+      if (i >= m) return;  // (uniform)
+      // the frame and its canvas origin are the same for the whole workgroup: scalar registers, a
+      // buffer descriptor per frame.  Rows above or below the frame give offsets outside the
+      // descriptor (the hardware returns 0, no branch); they are dropped through sh all the same
       const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]);
       const int ax = __builtin_amdgcn_readfirstlane(list_ax[i]), ay = __builtin_amdgcn_readfirstlane(list_ay[i]);
-      const int fx = X - ax, fy = Y - ay;
-      if (fy < 0 || fy >= H || fx + 3 < 0 || fx >= W) return;
-      const int fxc = min(max(fx, 0), W - 4);
       const size_t fbase = (size_t)g * (size_t)(H * W);
-      const uint32_t off = (uint32_t)(fy * W + fxc);
-      __builtin_memcpy(&raw, p.frames + fbase + off, 4);  // unaligned dword
-      if (p.mask) __builtin_memcpy(&mraw, p.mask + fbase + off, 4);
-      sh = fx - fxc;
+      const int fx = X - ax, fy = Y - ay;
+      const int fxc = min(max(fx, 0), W - 4);
+      const uint32_t voff = (uint32_t)(YW - ay * W + fxc);
+      raw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blit_rsrc(p.frames + fbase, (uint32_t)(H * W)), voff, 0, 0);
+      if (p.mask) mraw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blit_rsrc(p.mask + fbase, (uint32_t)(H * W)), voff, 0, 0);
+      const bool inside = (uint32_t)fy < (uint32_t)H && (uint32_t)(fx + 3) < (uint32_t)(W + 3);
+      sh = inside ? fx - fxc : 8;
     };
     auto place = [](uint32_t w, int sh, uint32_t fill) {  // bytes of the clamped dword -> pixel order, `fill` elsewhere
       if (sh < 0) return (w << (8 * -sh)) | (fill >> (32 + 8 * sh));
@@ -290,18 +296,20 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
     };
     auto apply = [&](uint32_t raw, uint32_t mraw, int sh) {
       if (sh == 8) return;
-      uint32_t w = place(raw & 0x0f0f0f0fu, sh, 0xffffffffu);  // 0xff in a byte = "outside the frame"
+      uint32_t w = place(raw & 0x0f0f0f0fu, sh, 0x10101010u);  // 0x10 in a byte = "outside the frame"
       if (p.mask) {
         const uint32_t mw = place(mraw, sh, 0u);
         const uint32_t nz = (((mw & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw) & 0x80808080u;  // bit 7 of every non-zero byte
-        w |= (nz >> 7) * 0xffu;                                                        // masked pixel -> "outside"
+        const uint32_t out = nz >> 3;                                                  // 0x10 per masked pixel
+        w = (w & ~(out - (out >> 4))) | out;                                           // masked pixel -> "outside"
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const uint32_t v = (w >> (8 * j)) & 0xffu;
-        // branch-free: a pixel outside the frame (0xff) adds 0 to a bin of its own slot
-        const uint32_t inc = v == 0xffu ? 0u : ((v & 1u) ? 0x10000u : 1u);
-        __hip_atomic_fetch_add(&bins[(v >> 1) & 7u][slot0 + (uint32_t)j * 32], inc, __ATOMIC_RELAXED,
+        // branch-free, five VALU ops per pixel: colour c adds 1 to half c & 1 of dword c >> 1;
+        // "outside" (16) adds to the ninth row (a compare-and-select to add 0 instead: ten)
+        const uint32_t v = (w >> (8 * j)) & 0x1fu;
+        const uint32_t inc = 1u + (v & 1u) * 0xffffu;
+        __hip_atomic_fetch_add(&bins[v >> 1][slot0 + (uint32_t)j * 32], inc, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_WORKGROUP);
       }
     };
