@@ -157,6 +157,24 @@ int rmx_frc_scan(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint
                  int first_is_start, int32_t carry_pos[2], uint32_t* carry_frag,
                  int32_t* pos, uint32_t* frag_id);
 
+/* The same state update for a stream sharded over ranks by contiguous blocks of frames
+ * (SURVEY.md §8e), without a host round trip between its steps — all three enqueue on the
+ * context's stream:
+ *   rmx_frc_scan_block   scans this rank's block as if the stream began there (first_is_start
+ *                        = 1 on the rank that really holds frame 0) and writes the block's scan
+ *                        summary {has a fragment start, x, y of its last frame relative to that
+ *                        start or to the block's begin, number of starts} to `summary` (4 int32,
+ *                        device) — what the ranks exchange (one 16-byte all-gather);
+ *   rmx_frc_apply_blocks folds the summaries of the blocks before `rank` (world x 4 int32,
+ *                        device, rank order) and moves the block into place: pos and frag_id
+ *                        become what rmx_frc_scan over the whole stream gives (frc.hpp:109-115);
+ *   rmx_frc_finish       synchronises once; *nfrag = fragments of the whole stream. */
+int rmx_frc_scan_block(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint32_t n,
+                       int first_is_start, int32_t* pos, uint32_t* frag_id, int32_t* summary);
+int rmx_frc_apply_blocks(rmx_ctx* ctx, const int32_t* summaries, uint32_t rank, uint32_t world,
+                         int32_t* pos, uint32_t* frag_id, uint32_t n);
+int rmx_frc_finish(rmx_ctx* ctx, uint32_t* nfrag);
+
 /* ---- fgm: fragment canvas ------------------------------------------------------------- */
 
 /* fgm::fragment::blit(pos, image, packed, no) (fgm.hpp:87-97,176-188) for a batch of

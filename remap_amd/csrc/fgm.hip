@@ -16,6 +16,7 @@ struct ScanParams {
   uint32_t n;
   uint32_t first_is_start;
   int32_t carry_in[3];  // the carry on entry (by value: no upload)
+  int32_t* summary;     // optional, device: the block's scan summary [has a start, x, y, starts] (out)
 };
 
 // Summary of a run of frames: did it contain a fragment start, the position offset since the
@@ -115,6 +116,48 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
     p.carry[0] = s_carry.x;
     p.carry[1] = s_carry.y;
     p.carry[2] = s_carry.c;
+    if (p.summary) {
+      p.summary[0] = (p.first_is_start || s_carry.c > 0) ? 1 : 0;
+      p.summary[1] = s_carry.x;
+      p.summary[2] = s_carry.y;
+      p.summary[3] = s_carry.c;
+    }
+  }
+}
+
+// Frame-sharded streams: every rank scans its block as if the stream began there and publishes
+// the block's summary; this kernel folds the summaries of the blocks before `rank` (the same
+// associative rule as the scan) and moves the block into place — positions of the frames that
+// continue the previous block's fragment (local fragment 0) by the carried position, all
+// fragment numbers by the carried count.  No host round trip between scan, exchange and fix-up.
+struct ApplyParams {
+  const int32_t* summaries;  // world x 4
+  int32_t* pos;
+  uint32_t* frag;
+  uint32_t* nfrag_out;  // fragments of the whole stream
+  uint32_t n, rank, world;
+};
+__global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
+  int32_t ax = 0, ay = 0;
+  uint32_t ac = 0, all = 0;
+  for (uint32_t q = 0; q < p.world; ++q) {  // (world is small; every thread folds for itself)
+    const int32_t r = p.summaries[4 * q], x = p.summaries[4 * q + 1], y = p.summaries[4 * q + 2];
+    const uint32_t c = (uint32_t)p.summaries[4 * q + 3];
+    if (q < p.rank) {
+      ax = r ? x : ax + x;
+      ay = r ? y : ay + y;
+      ac += c;
+    }
+    all += c;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *p.nfrag_out = all + 1;
+  for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
+    const uint32_t fl = p.frag[i];
+    if (fl == 0) {
+      p.pos[2 * i] += ax;
+      p.pos[2 * i + 1] += ay;
+    }
+    p.frag[i] = fl + ac;
   }
 }
 

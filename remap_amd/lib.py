@@ -29,7 +29,7 @@ STATUS = {0: "RMX_OK", -1: "RMX_ERR_ARG", -2: "RMX_ERR_DEVICE", -3: "RMX_ERR_KMA
 # every symbol include/remap_amd.h declares
 SYMBOLS = [
     "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
-    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_fgm_blit_batch", "rmx_fgm_extent",
+    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_frc_scan_block", "rmx_frc_apply_blocks", "rmx_frc_finish", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
@@ -99,6 +99,9 @@ def load():
     lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
+    lib.rmx_frc_scan_block.argtypes = [vp, vp, vp, u32, C.c_int, vp, vp, vp]
+    lib.rmx_frc_apply_blocks.argtypes = [vp, vp, u32, u32, vp, vp, u32]
+    lib.rmx_frc_finish.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_fgm_blit_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32, i32, i32]
     lib.rmx_fgm_extent.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32),
                                    C.POINTER(i32)]
@@ -278,6 +281,31 @@ class Context:
         self._chk(self.lib.rmx_frc_scan(self.h, dxdy.data_ptr(), matched.data_ptr(), n, int(first_is_start), cp,
                                         C.byref(cf), pos.data_ptr(), frag.data_ptr()), "rmx_frc_scan")
         return pos, frag, ((cp[0], cp[1]), cf.value)
+
+    def frc_scan_block(self, dxdy, matched, first_is_start):
+        """This rank's block scanned on its own (no synchronisation): (pos, frag, summary) device
+        tensors; summary = the 4 int32 the ranks exchange."""
+        t = self.torch
+        n = dxdy.shape[0]
+        pos = t.empty((n, 2), dtype=t.int32, device=self.device)
+        frag = t.empty(n, dtype=t.int32, device=self.device)
+        summ = t.empty((1, 4), dtype=t.int32, device=self.device)
+        self._chk(self.lib.rmx_frc_scan_block(self.h, dxdy.data_ptr(), matched.data_ptr(), n, int(first_is_start),
+                                              pos.data_ptr(), frag.data_ptr(), summ.data_ptr()), "rmx_frc_scan_block")
+        return pos, frag, summ
+
+    def frc_apply_blocks(self, summaries, rank, world, pos, frag):
+        """Fold the summaries of the blocks before `rank` into pos / frag (in place, no synchronisation)."""
+        assert summaries.is_cuda and summaries.dtype == self.torch.int32 and summaries.is_contiguous()
+        assert summaries.numel() == 4 * world
+        self._chk(self.lib.rmx_frc_apply_blocks(self.h, summaries.data_ptr(), rank, world, pos.data_ptr(), frag.data_ptr(),
+                                                pos.shape[0]), "rmx_frc_apply_blocks")
+
+    def frc_finish(self):
+        """Synchronise; fragments of the whole stream (also caches the status words)."""
+        nf = C.c_uint32(0)
+        self._chk(self.lib.rmx_frc_finish(self.h, C.byref(nf)), "rmx_frc_finish")
+        return nf.value
 
     # ---- fdf -------------------------------------------------------------------------------
     def fdf_filter(self, bg, frames, medians, pos, canvas=None, check=True):

@@ -189,18 +189,18 @@ class Aligner:
             if self.rank > 0:
                 halo = (tabs[self.rank - 1].contiguous(), cnts[self.rank - 1:self.rank].contiguous())
         dxdy, matched = ctx.kpm_seq(desc, kcount, halo=halo)
-        pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=(self.rank == 0))  # synchronises
-        nfrag = carry[1] + 1
-        if self.world > 1:
-            # this block's summary: did a fragment start in it, where its last frame sits
-            # relative to that start (or to the block's begin), how many starts
-            mine = t.tensor([[int(carry[1] > 0 or self.rank == 0), carry[0][0], carry[0][1], carry[1]]],
-                            dtype=t.int32, device=frames.device)
-            summ = _all_gather_flat(mine, self.world, self.dist, self.group).cpu().numpy()
-            carry_in = fold_block_summaries(summ, self.rank)
-            nfrag = int(summ[:, 3].sum()) + 1
-            if self.rank > 0:
-                pos, frag, _ = ctx.frc_scan(dxdy, matched, first_is_start=False, carry=carry_in)
+        if self.world == 1:
+            pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)  # synchronises
+            nfrag = carry[1] + 1
+        else:
+            # every rank scans its block on its own; the blocks' 16-byte summaries (did a fragment
+            # start in it, where its last frame sits relative to that start or to the block's
+            # begin, how many starts) are exchanged and folded ON THE DEVICE: scan, all-gather and
+            # fix-up are enqueued back to back, the host waits once
+            pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
+            summ = _all_gather_flat(mine, self.world, self.dist, self.group)
+            ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
+            nfrag = ctx.frc_finish()
         out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
                    lo=lo, hi=hi, nfrag=nfrag, n_total=n_total)
         if check:

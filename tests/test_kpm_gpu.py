@@ -173,3 +173,32 @@ def test_kpm_build_tiers_between_sparse_and_dense(gpu, dens):
     per_region = [np.bincount(np.concatenate([np.flatnonzero([(m >> r) & 1 for m in t["region_mask"]]) * 0 + r for r in range(8)]),
                               minlength=8).max() for t in g["tabs"]]
     assert max(per_region) > 16  # beyond the 16-key network
+
+
+def test_frc_block_scan_equals_whole_stream_scan(gpu):
+    """rmx_frc_scan_block + rmx_frc_apply_blocks (the frame-sharded chain without host round
+    trips) over 1..5 blocks of a stream with breaks = rmx_frc_scan over the whole stream."""
+    import torch
+
+    rng = np.random.default_rng(3)
+    ctx = L.Context(320, 240)
+    for trial in range(6):
+        n = int(rng.integers(40, 4000))
+        dxdy = torch.from_numpy(rng.integers(-4, 5, size=(n, 2)).astype(np.int32)).cuda()
+        m = (rng.random(n) > (0.0, 0.02, 0.3, 0.9, 1.0, 0.5)[trial]).astype(np.uint8)
+        if trial == 5:
+            m[: n // 2] = 1  # no break in the first blocks: carries run across several of them
+        matched = torch.from_numpy(m).cuda()
+        pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
+        for world in (1, 2, 3, 5):
+            cuts = [0] + sorted(rng.choice(np.arange(1, n), size=world - 1, replace=False).tolist()) + [n]
+            parts = [ctx.frc_scan_block(dxdy[a:b].contiguous(), matched[a:b].contiguous(), first_is_start=(r == 0))
+                     for r, (a, b) in enumerate(zip(cuts[:-1], cuts[1:]))]
+            summ = torch.cat([p[2] for p in parts]).contiguous()
+            for r, (pp, ff, _) in enumerate(parts):
+                ctx.frc_apply_blocks(summ, r, world, pp, ff)
+            nfrag = ctx.frc_finish()
+            assert nfrag == carry[1] + 1
+            assert torch.equal(torch.cat([p[0] for p in parts]), pos), (trial, world)
+            assert torch.equal(torch.cat([p[1] for p in parts]), frag), (trial, world)
+    ctx.close()
