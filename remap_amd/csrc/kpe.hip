@@ -211,9 +211,8 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
     uint32_t pk = merge_rows(A, B, Cn);                                                  \
     store_row(yy, pk & maskx);                                                           \
     uint32_t t = ((((pk ^ B.key) & maskx) + 0x0f0f0f0fu) & 0x10101010u);                 \
-    const uint32_t r = (uint32_t)yy & 7u;                                                \
-    C |= r < 4 ? t << r : (t >> 4) << (r - 4);                                           \
-    if (r == 7u) {                                                                       \
+    C = (t << 3) | (C >> 1); /* bit 7 of the pixel's byte, older rows move down */    \
+    if (((uint32_t)yy & 7u) == 7u) {                                                     \
       store_cand(yy >> 3, C);                                                            \
       C = 0;                                                                             \
     }                                                                                    \
@@ -234,7 +233,7 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   if (y + 4 < vy1) RMX_STEP(T1, T2, T0, pf4, 4)
 #undef RMX_STEP
   // last (partial) block of the strip and blocks that hold only border rows
-  if ((vy1 & 7) != 0) store_cand(vy1 >> 3, C);
+  if ((vy1 & 7) != 0) store_cand(vy1 >> 3, C >> (8 - (vy1 & 7)));  // the block's last rows are missing: finish the shifts
   for (int yb = (vy1 + 7) >> 3; yb * 8 < y1; ++yb) store_cand(yb, 0u);
 }
 
@@ -399,7 +398,7 @@ __global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
     }
     const uint32_t gw = w0 + wi, yb = gw / p.Wd, c = gw - yb * p.Wd;
     x = c * 4 + (b >> 3);
-    y = yb * 8 + ((b & 7u) ^ 4u);
+    y = yb * 8 + (b & 7u);
   };
 
   for (uint32_t k0 = 0; k0 < total; k0 += 512) {

@@ -83,7 +83,8 @@ def load():
     # process do not share devices, streams or allocations.
     import torch  # noqa: F401
 
-    lib = C.CDLL(SO_PATH)
+    # RMX_SO: another build of the library for A/B timings on one box (tools/), never set by tests/bench
+    lib = C.CDLL(os.environ.get("RMX_SO") or SO_PATH)
     vp, u32, i32 = C.c_void_p, C.c_uint32, C.c_int32
     lib.rmx_version.restype = C.c_char_p
     lib.rmx_last_error.restype = C.c_char_p
