@@ -95,13 +95,18 @@ __device__ __forceinline__ bool fdf_run_head(uint32_t root, uint32_t x, uint32_t
 // whole-frame union-find in HBM with one thread per pixel: init 268 + merge 856 us, and 700 us
 // for fdf_stats to walk the chains it left.
 #ifndef FDF_TILE_PX
-#define FDF_TILE_PX 7680
+#define FDF_TILE_PX 3840
 #endif
-constexpr uint32_t FDF_TILE = FDF_TILE_PX;  // pixels of a strip (5 B of LDS each: 37.5 KB, four workgroups per CU)
+// pixels of a strip (5 B of LDS each: 19 KB, eight workgroups per CU).  Per 833 frames 320x240,
+// local + stitch + stats: 7680 -> 319 + 28 + 232 us, 5120 -> 263 + 44 + 245, 3840 -> 212 + 60 + 251,
+// 2560 -> 206 + 92 + 260: smaller strips label faster and leave more to stitch and longer chains
+constexpr uint32_t FDF_TILE = FDF_TILE_PX;
+constexpr uint32_t FDF_TILE_WIDE = 2 * FDF_TILE;  // the instance for frames wider than FDF_TILE
 
+template <uint32_t TILE>
 __global__ __launch_bounds__(256) void fdf_local(FdfParams p, uint32_t R, uint32_t S) {
-  __shared__ uint32_t lab[FDF_TILE];
-  __shared__ uint8_t col[FDF_TILE];
+  __shared__ uint32_t lab[TILE];
+  __shared__ uint8_t col[TILE];
   const uint32_t f = blockIdx.x / S, s = blockIdx.x - f * S, tid = threadIdx.x, lane = tid & 63u;
   const uint32_t W = p.W, P = p.W * p.H;
   const uint32_t ys = 1 + s * R, ye = min(ys + R, p.H >= 2 ? p.H - 2 : 0u);  // interior rows [ys, ye)
