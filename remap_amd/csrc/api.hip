@@ -47,6 +47,8 @@ struct rmx_ctx {
   bool status_cached = false;
   KpmWorkspace kpm{};
   uint32_t* blit_ws = nullptr;  // fgm_blit binning workspace
+  void* pack_buf = nullptr;     // staging of rmx_download_2d
+  size_t pack_cap = 0;
   void* fdf_ws = nullptr;       // foreground-filter labelling workspace for fdf_cap frames
   uint32_t fdf_cap = 0;
   size_t blit_ws_bytes = 0;
@@ -110,6 +112,15 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   ctx->n_cap = n;
   ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + cand_bytes + kpm_workspace_bytes(ctx->kpm);
   return RMX_OK;
+}
+
+// rows of `width` bytes, `spitch` apart, packed back to back (2-byte units: descriptor rows)
+__global__ __launch_bounds__(256) void pack_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, size_t spitch2,
+                                                 uint32_t width2, size_t total2) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total2) return;
+  const size_t row = i / width2;
+  dst[i] = src[row * spitch2 + (i - row * width2)];
 }
 
 __global__ __launch_bounds__(256) void copy_stream(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n) {
@@ -212,6 +223,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->status) (void)hipFree(ctx->status);
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->fdf_ws) (void)hipFree(ctx->fdf_ws);
+  if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
   for (auto e : ctx->ev_main) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_fin) (void)hipEventDestroy(e);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -323,6 +335,28 @@ int rmx_download_2d(rmx_ctx* ctx, void* dst, size_t dpitch, const void* src, siz
   if (!ctx || !dst || !src || width > dpitch || width > spitch) return RMX_ERR_ARG;
   if (width == 0 || rows == 0) return RMX_OK;
   RMX_HIP(hipSetDevice(ctx->device));
+  // many short rows into one tight block (a block of descriptor tables cut to the rows in use):
+  // packed on the device, then ONE linear copy — a 2-D DMA of 16 384 rows of ~1 KB took 80 ms
+  const uintptr_t al = reinterpret_cast<uintptr_t>(src) | spitch | width;
+  if (dpitch == width && (al & 1u) == 0 && rows > 64) {
+    const size_t bytes = width * rows;
+    if (bytes > ctx->pack_cap) {
+      RMX_HIP(hipStreamSynchronize(ctx->stream));
+      if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
+      ctx->pack_buf = nullptr;
+      ctx->pack_cap = 0;
+      RMX_HIP(hipMalloc(&ctx->pack_buf, bytes));
+      ctx->pack_cap = bytes;
+    }
+    const size_t total2 = bytes / 2;
+    hipLaunchKernelGGL(pack_rows, dim3((uint32_t)((total2 + 255) / 256)), dim3(256), 0, ctx->stream,
+                       static_cast<const uint16_t*>(src), static_cast<uint16_t*>(ctx->pack_buf), spitch / 2, (uint32_t)(width / 2),
+                       total2);
+    RMX_HIP(hipGetLastError());
+    RMX_HIP(hipMemcpyAsync(dst, ctx->pack_buf, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    RMX_HIP(hipStreamSynchronize(ctx->stream));
+    return RMX_OK;
+  }
   RMX_HIP(hipMemcpy2DAsync(dst, dpitch, src, spitch, width, rows, hipMemcpyDeviceToHost, ctx->stream));
   RMX_HIP(hipStreamSynchronize(ctx->stream));
   return RMX_OK;
