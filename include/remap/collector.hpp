@@ -12,8 +12,10 @@
 // promises.  Nothing is computed on the host.
 #pragma once
 
+#include <exception>
 #include <list>
 #include <optional>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -265,6 +267,41 @@ public:
         pk_median = nic::detail::compress_device(ctx_, median_.get<std::uint8_t>(), n, std::uint32_t(area));
       }
       clk.mark("codec");
+      // ---- the per-frame host objects the callbacks borrow (median image, keypoint grid): built
+      // by worker threads, each out of its own arena; the callbacks below stay on this thread,
+      // once per frame in frame order (frc.hpp:119).  One thread: 22 us per frame, the largest
+      // share of a host-bound collect ----
+      const unsigned workers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+      std::vector<all::memory_pool> arenas(workers);
+      std::vector<std::optional<image_type>> medians(n);
+      std::vector<std::optional<grid_type>> grids(n);
+      {
+        std::vector<std::exception_ptr> failed(workers);
+        // (the staging buffers are thread_local: the workers get this thread's pointers)
+        const std::uint8_t* med_src = h_med_.template get<std::uint8_t>();
+        const auto* tab_src = h_tab_.data();
+        const auto* k_src = h_k_.data();
+        auto prepare = [&, med_src, tab_src, k_src](unsigned w) {
+          try {
+            for (std::uint32_t t = w; t < n; t += workers) {
+              medians[t].emplace(dim_, pixel_alloc_t{arenas[w]});
+              std::memcpy(medians[t]->data(), med_src + t * area, area);
+              if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
+              grids[t].emplace(remap::detail::table_to_grid<grid_type>(tab_src + std::size_t(t) * tstride, k_src[t],
+                                                                       allocator_t<char>{arenas[w]}));
+            }
+          } catch (...) {
+            failed[w] = std::current_exception();
+          }
+        };
+        std::vector<std::thread> pool_threads;
+        for (unsigned w = 1; w < workers; ++w) pool_threads.emplace_back(prepare, w);
+        prepare(0);
+        for (auto& th : pool_threads) th.join();
+        for (auto& e : failed)
+          if (e) std::rethrow_exception(e);
+      }
+      clk.mark("host objects (medians, grids; worker threads)");
       // ---- device blit of the block, fragment by fragment (frc.hpp:129-135) ----
       for (std::uint32_t i = 0; i < n;) {
         std::uint32_t j = i;
@@ -279,8 +316,7 @@ public:
                      ctx_, "rmx_fgm_blit_batch");
         // ---- replay: bookkeeping + callback per frame, in order (frc.hpp:117-119) ----
         for (std::uint32_t t = i; t < j; ++t) {
-          image_type median{dim_, pixel_alloc_t{pool}};
-          std::memcpy(median.data(), h_med_.get<std::uint8_t>() + t * area, area);
+          image_type const& median = *medians[t];
           fgm::point_t p{h_pos_[2 * t], h_pos_[2 * t + 1]};
           if constexpr (device_codec)
             current_->frames_.emplace_back(
@@ -289,14 +325,12 @@ public:
             current_->frames_.emplace_back(
                 fgm::frame{block[t].number_, p, fgm::packed_data{comp(block[t].image_), comp(median)}});
           if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
-          grid_type keys = remap::detail::table_to_grid<grid_type>(h_tab_.data() + std::size_t(t) * tstride, h_k_[t],
-                                                                   allocator_t<char>{pool});
-          cb(*current_, block[t], median, keys);
+          cb(*current_, block[t], median, *grids[t]);
         }
         i = j;
       }
       remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
-      clk.mark("blit + replay (grids, medians, callbacks)");
+      clk.mark("blit + replay (callbacks)");
       first = false;
     }
   }
