@@ -218,7 +218,17 @@ public:
       reserve(n);
       // frames are gathered in page-locked memory and cross PCIe in one copy
       stage_.reserve(ctx_, std::size_t(n) * area);
-      for (std::uint32_t i = 0; i < n; ++i) std::memcpy(stage_.get<std::uint8_t>() + i * area, block[i].image_.data(), area);
+      {
+        std::uint8_t* stage = stage_.template get<std::uint8_t>();  // (thread_local: this thread's buffer)
+        const unsigned gatherers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+        auto gather = [&, stage](unsigned w) {
+          for (std::uint32_t i = w; i < n; i += gatherers) std::memcpy(stage + i * area, block[i].image_.data(), area);
+        };
+        std::vector<std::thread> helpers;
+        for (unsigned w = 1; w < gatherers; ++w) helpers.emplace_back(gather, w);
+        gather(0);
+        for (auto& th : helpers) th.join();
+      }
       remap::check(rmx_upload(ctx_, frames_.get<std::uint8_t>(), stage_.get(), std::size_t(n) * area), ctx_, "rmx_upload");
       clk.mark("stage + upload");
       // ---- the hot path, all on the device ----
