@@ -755,8 +755,8 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint3
   return incl - v;
 }
 
-// RC = entries per region the instance holds (256: 70 KB of LDS, two workgroups per CU;
-// 512: 139 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
+// RC = entries per region the instance holds (256: 53 KB of LDS, three workgroups per CU;
+// 512: 104 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
 template <uint32_t RC, uint32_t TIN>
 __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, uint32_t* tier, uint32_t fslot) {
   // (the map-order scratch lives in arrays that are dead by then: see the umap_order_par call;
@@ -1063,7 +1063,7 @@ __device__ inline void exact_top3(const uint32_t* hk, const uint32_t* hc, const 
 // frame 0), previous frame = q - 1 (pool slot n for the halo).
 // Three instances behind kpm_match_pair, each walking the work list the one before it
 // appended to (fixed grids, no host round trip).  Offset slots / shared codes / distinct
-// offsets: TIER 0 = 256 / 256 / 128 (9 KB of LDS; the dense stream: ~110 shared codes but
+// offsets: TIER 0 = 256 / 256 / 128 (8 KB of LDS; the dense stream: ~110 shared codes but
 // only a handful of distinct offsets per region), TIER 1 = 1024 / 1024 / 512 (39 KB),
 // TIER 2 = 4096 / 2048 / 2048 (136 KB: one wave per CU), which flags the status word
 // instead of passing on.
