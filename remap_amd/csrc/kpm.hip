@@ -1403,64 +1403,104 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
   const uint32_t* p_pts = P + kpm_off_pts(p.kmax);
 
   // ---- a. shared codes, region by region in each current map's iteration order ----
+  // (Gtot <= 128: both chunks of 64 codes walk their chains of dependent loads side by side)
   uint32_t nm = 0, total = 0;
-  for (uint32_t base = 0; base < Gtot; base += 64) {
-    const uint32_t k = min(base + lane, Gtot - 1);
-    uint32_t r = 0, jbase = 0;
+  {
+    uint32_t rg[2], gcv[2], c[2][4], sl[2], pv[2], goff_c[2], goff_p[2], htoff[2], pmask[2];
+    uint32_t pairs[2], ps[2], cs[2], nc[2];
+    bool pend[2], hit[2];
 #pragma unroll
-    for (int q2 = 1; q2 < 8; ++q2)
-      if (k >= gpre[q2]) {
-        r = q2;
-        jbase = gpre[q2];
-      }
-    // (a region without codes has zero width, so the last boundary <= k names k's region)
-    const uint32_t goff_c = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_GOFF));
-    const uint32_t w2c = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_W2));
-    const uint32_t goff_p = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_GOFF));
-    const uint32_t htoff = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTOFF));
-    const uint32_t pmask = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTMASK));
-    const uint32_t w2p = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_W2));
-    uint32_t pairs = 0, ps = 0, cs = 0, nc = 0;
-    if (base + lane < Gtot) {
-      // kpm.hpp:219-222: all codes unless both regions are rich in weight-2 keypoints
-      const bool use_all = w2p < p.weight_switch || w2c <= p.weight_switch;
-      const uint32_t gc = c_giter[goff_c + (k - jbase)];
-      uint32_t c[4];
-      load_gcode(Cc, p.kmax, goff_c + gc, c);
-      if (use_all || (c[3] & 0xfu) == 2u) {
-        uint32_t s = fnv_code_lo(c) & pmask;
-        for (;;) {
-          const uint32_t v = p_ht[htoff + s];
-          if (v == 0) break;
-          uint32_t c2[4];
-          load_gcode(P, p.kmax, goff_p + v - 1, c2);
-          if (same_code(c, c2)) {
-            ps = p_gstart[goff_p + r + v - 1];
-            cs = c_gstart[goff_c + r + gc];
-            nc = c_gstart[goff_c + r + gc + 1] - cs;
-            pairs = (p_gstart[goff_p + r + v] - ps) * nc;
-            break;
-          }
-          s = (s + 1) & pmask;
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t k = min(64u * u + lane, Gtot - 1);
+      uint32_t r = 0, jbase = 0;
+#pragma unroll
+      for (int q2 = 1; q2 < 8; ++q2)
+        if (k >= gpre[q2]) {
+          r = q2;
+          jbase = gpre[q2];
         }
+      // (a region without codes has zero width, so the last boundary <= k names k's region)
+      rg[u] = r;
+      goff_c[u] = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_GOFF));
+      const uint32_t w2c = (uint32_t)__shfl((int)hcu, (int)(r * 8 + H_W2));
+      goff_p[u] = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_GOFF));
+      htoff[u] = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTOFF));
+      pmask[u] = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_HTMASK));
+      const uint32_t w2p = (uint32_t)__shfl((int)hp, (int)(r * 8 + H_W2));
+      pend[u] = 64u * u + lane < Gtot;
+      // kpm.hpp:219-222: all codes unless both regions are rich in weight-2 keypoints
+      hit[u] = w2p < p.weight_switch || w2c <= p.weight_switch;  // (use_all, until the codes are here)
+      gcv[u] = pend[u] ? c_giter[goff_c[u] + (k - jbase)] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      c[u][0] = c[u][1] = c[u][2] = c[u][3] = 0;
+      if (pend[u]) load_gcode(Cc, p.kmax, goff_c[u] + gcv[u], c[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pend[u] = pend[u] && (hit[u] || (c[u][3] & 0xfu) == 2u);
+      hit[u] = false;
+      sl[u] = fnv_code_lo(c[u]) & pmask[u];
+      pv[u] = 0;
+    }
+    for (;;) {  // probe rounds: the pending lookups of all lanes advance together
+      uint32_t v[2], c2[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) v[u] = pend[u] ? p_ht[htoff[u] + sl[u]] : 0u;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        pend[u] = pend[u] && v[u] != 0;
+        c2[u][0] = c2[u][1] = c2[u][2] = c2[u][3] = 0;
+        if (pend[u]) load_gcode(P, p.kmax, goff_p[u] + v[u] - 1, c2[u]);
+      }
+      bool more = false;
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+        if (pend[u]) {
+          if (same_code(c[u], c2[u])) {
+            pv[u] = v[u];
+            hit[u] = true;
+            pend[u] = false;
+          } else {
+            sl[u] = (sl[u] + 1) & pmask[u];
+            more = true;
+          }
+        }
+      if (__builtin_amdgcn_ballot_w64(more) == 0) break;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pairs[u] = ps[u] = cs[u] = nc[u] = 0;
+      if (hit[u]) {
+        const uint32_t p0 = p_gstart[goff_p[u] + rg[u] + pv[u] - 1], p1 = p_gstart[goff_p[u] + rg[u] + pv[u]];
+        const uint32_t c0 = c_gstart[goff_c[u] + rg[u] + gcv[u]], c1 = c_gstart[goff_c[u] + rg[u] + gcv[u] + 1];
+        ps[u] = p0;
+        cs[u] = c0;
+        nc[u] = c1 - c0;
+        pairs[u] = (p1 - p0) * nc[u];
       }
     }
-    const uint64_t bal = __builtin_amdgcn_ballot_w64(pairs != 0);
-    uint32_t incl = pairs;
 #pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-      if (lane >= (uint32_t)o) incl += t;
+    for (int u = 0; u < 2; ++u) {
+      if (64u * u >= Gtot) continue;  // uniform
+      const uint64_t bal = __builtin_amdgcn_ballot_w64(pairs[u] != 0);
+      uint32_t incl = pairs[u];
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += t;
+      }
+      if (pairs[u] != 0) {
+        const uint32_t at = nm + mbcnt(bal);
+        mg_p[at] = ps[u];
+        mg_c[at] = cs[u] | rg[u] << 20;
+        mg_n[at] = nc[u];
+        mg_base[at] = total + incl - pairs[u];
+      }
+      total += (uint32_t)__shfl((int)incl, 63);
+      nm += (uint32_t)__builtin_popcountll(bal);
     }
-    if (pairs != 0) {
-      const uint32_t at = nm + mbcnt(bal);
-      mg_p[at] = ps;
-      mg_c[at] = cs | r << 20;
-      mg_n[at] = nc;
-      mg_base[at] = total + incl - pairs;
-    }
-    total += (uint32_t)__shfl((int)incl, 63);
-    nm += (uint32_t)__builtin_popcountll(bal);
   }
   if (nm == 0) return;
   if (lane == 0) mg_base[nm] = total;
@@ -1474,33 +1514,56 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
 
   // ---- b. count_offsets: previous outer, current inner (kpm.hpp:94-95), one table per region ----
   uint32_t fail = 0;
-  for (uint32_t t = lane; t < total; t += 64) {
-    uint32_t lo = 0, hi = nm;
-    while (hi - lo > 1) {
-      const uint32_t mid = (lo + hi) >> 1;
-      if (mg_base[mid] <= t)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    const uint32_t nc = mg_n[lo], rel = t - mg_base[lo], cw = mg_c[lo], r = cw >> 20;
-    const uint32_t ip = rel / nc, ic = rel - ip * nc;
-    const uint32_t pp = p_pts[mg_p[lo] + ip], cp = c_pts[(cw & 0xfffffu) + ic];
-    const int32_t dx = (int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu);
-    const int32_t dy = (int32_t)(pp >> 16) - (int32_t)(cp >> 16);
-    const uint32_t key = off_key(dx, dy), tb = r * PW_SLOTS;
-    uint32_t s = (key * 2654435761u) >> 27;
-    for (uint32_t probes = 0;; ++probes) {
-      const uint32_t v = atomicCAS(&hk[tb + s], 0u, key);
-      if (v == 0u || v == key) {
-        atomicAdd(&hc[tb + s], 1u);
-        atomicMin(&hs[tb + s], t);
-        break;
+  for (uint32_t t0 = 0; t0 < total; t0 += 128) {  // two pairs per lane: their point loads in flight together
+    uint32_t pi[2], ci[2], rr2[2];
+    bool act[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const uint32_t t = t0 + 64u * u + lane;
+      act[u] = t < total;
+      pi[u] = ci[u] = rr2[u] = 0;
+      if (act[u]) {
+        uint32_t lo = 0, hi = nm;
+        while (hi - lo > 1) {
+          const uint32_t mid = (lo + hi) >> 1;
+          if (mg_base[mid] <= t)
+            lo = mid;
+          else
+            hi = mid;
+        }
+        const uint32_t nc = mg_n[lo], rel = t - mg_base[lo], cw = mg_c[lo];
+        const uint32_t ip = rel / nc, ic = rel - ip * nc;
+        rr2[u] = cw >> 20;
+        pi[u] = mg_p[lo] + ip;
+        ci[u] = (cw & 0xfffffu) + ic;
       }
-      s = (s + 1) & (PW_SLOTS - 1);
-      if (probes >= PW_SLOTS) {
-        fail |= 1u << r;
-        break;
+    }
+    uint32_t pp[2], cp[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      pp[u] = act[u] ? p_pts[pi[u]] : 0u;
+      cp[u] = act[u] ? c_pts[ci[u]] : 0u;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (!act[u]) continue;
+      const uint32_t t = t0 + 64u * u + lane, r = rr2[u];
+      const int32_t dx = (int32_t)(pp[u] & 0xffffu) - (int32_t)(cp[u] & 0xffffu);
+      const int32_t dy = (int32_t)(pp[u] >> 16) - (int32_t)(cp[u] >> 16);
+      const uint32_t key = off_key(dx, dy), tb = r * PW_SLOTS;
+      uint32_t s = (key * 2654435761u) >> 27;
+      for (uint32_t probes = 0;; ++probes) {
+        const uint32_t v = atomicCAS(&hk[tb + s], 0u, key);
+        if (v == 0u || v == key) {
+          atomicAdd(&hc[tb + s], 1u);
+          atomicMin(&hs[tb + s], t);
+          break;
+        }
+        s = (s + 1) & (PW_SLOTS - 1);
+        if (probes >= PW_SLOTS) {
+          fail |= 1u << r;
+          break;
+        }
       }
     }
   }
