@@ -172,8 +172,9 @@ __global__ __launch_bounds__(256) void fdf_stitch(FdfParams p, uint32_t R, uint3
 
 // fdf_stats and fdf_keep walk label -> root -> statistics: chains of dependent loads.  A thread
 // takes FDF_PPT pixels (256 apart, so a wave still holds 64 consecutive pixels of each) and
-// issues the loads of all of them side by side (one pixel per thread: 645 / 247 us per 833 frames).
-constexpr uint32_t FDF_PPT = 4;
+// issues the loads of all of them side by side (per 833 frames, stats / keep: one pixel per
+// thread 645 / 247 us, four 251 / 94, eight 226 / 78).
+constexpr uint32_t FDF_PPT = 8;
 
 __global__ __launch_bounds__(256) void fdf_stats(FdfParams p) {
   // grid: x = frame, y = chunk of 256 * FDF_PPT pixels of it (no 64-bit divisions per pixel)
