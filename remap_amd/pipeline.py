@@ -60,11 +60,17 @@ def gather_boundary_tables(last_desc, last_k, dist=None, group=None):
     import torch
 
     world = dist.get_world_size(group)
-    # one flat buffer per rank: [count (4 bytes, little endian) | table bytes]
-    flat = torch.cat([last_k.reshape(1).to(torch.int32).view(torch.uint8), last_desc.reshape(-1)])
-    allf = _all_gather_flat(flat.contiguous(), world, dist, group).view(world, -1)
-    cnts = allf[:, :4].contiguous().view(torch.int32).reshape(world)
-    tabs = allf[:, 4:].reshape((world,) + tuple(last_desc.shape))
+    # one flat buffer per rank: [table bytes | count (4 bytes, little endian)] — the table first,
+    # so that every rank's table sits 4-byte aligned in the gathered buffer and can be used in
+    # place (a view, no copy) as the halo of rmx_kpm_seq
+    nb = last_desc.numel()
+    pad = (-nb) % 4
+    flat = torch.empty(nb + pad + 4, dtype=torch.uint8, device=last_desc.device)
+    flat[:nb].copy_(last_desc.reshape(-1))
+    flat[nb + pad:].copy_(last_k.reshape(1).to(torch.int32).view(torch.uint8))
+    allf = _all_gather_flat(flat, world, dist, group).view(world, -1)
+    cnts = allf[:, nb + pad:].view(torch.int32).reshape(world)  # (row stride is a multiple of 4)
+    tabs = allf[:, :nb].view((world,) + tuple(last_desc.shape))
     return tabs, cnts
 
 
