@@ -193,10 +193,25 @@ class collector {
 public:
   // frames staged per device block (a block of 320x240 frames is 75 KB/frame of HBM x3)
   static inline constexpr std::uint32_t block_frames = 4096;
+  // rows per descriptor table to start with; a frame with more keypoints makes the collector
+  // re-run its block with larger tables (the reference has no limit, kpr.hpp:121-124), up to
+  // the matcher's table stride
   static inline constexpr std::uint32_t kmax = 2048;
+  static inline constexpr std::uint32_t max_kmax = 16384;
 
   collector(mrl::dimensions_t d)
       : dim_{d}, ctx_{remap::context_cache::get(std::uint32_t(d.width_), std::uint32_t(d.height_), 4, 2, 16, kmax)} {}
+
+  // The callback of frc.hpp:119 borrows the current fragment.  By default a run of frames of one
+  // fragment is blitted in one launch BEFORE its callbacks are replayed, so a callback that
+  // reads the fragment's canvas (blend(), dots(), margins()) sees the frames of the whole run.
+  // exact_callbacks(true) blits and waits frame by frame: the callback of frame t then sees the
+  // canvas exactly after frame t, as the reference's does (frc.hpp:117-119) — at per-frame
+  // launch cost.  main.cpp's callback ignores the fragment (main.cpp:139-149).
+  collector& exact_callbacks(bool on) noexcept {
+    exact_callbacks_ = on;
+    return *this;
+  }
 
   template <typename Feeder, typename Comp, typename Callback>
   void collect(Feeder&& feed, Comp&& comp, Callback&& cb)
@@ -204,6 +219,7 @@ public:
   {
     const std::size_t area = dim_.area();
     bool first = true;
+    bool fresh = true;  // process_init always opens a fragment (frc.hpp:83-95), also on a second collect()
     std::int32_t carry_pos[2] = {0, 0};
     std::uint32_t carry_frag = 0;
     remap::detail::phase_clock clk;
@@ -215,6 +231,10 @@ public:
       while (feed.has_more() && block.size() < block_frames) block.push_back(feed.produce(pixel_alloc_t{pool}));
       const std::uint32_t n = std::uint32_t(block.size());
       clk.mark("feed.produce");
+      std::uint32_t maxk = 0;
+      const std::int32_t carry_pos0[2] = {carry_pos[0], carry_pos[1]};
+      const std::uint32_t carry_frag0 = carry_frag;
+      for (;;) {  // one pass, unless a frame has more keypoints than the tables hold
       reserve(n);
       // frames are gathered in page-locked memory and cross PCIe in one copy
       stage_.reserve(ctx_, std::size_t(n) * area);
@@ -238,19 +258,27 @@ public:
       remap::check(rmx_kpm_seq(ctx_, desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>(), n,
                                first ? nullptr : halo_.get<rmx_desc>(),
                                first ? nullptr : reinterpret_cast<std::uint32_t const*>(
-                                                     halo_.get<std::uint8_t>() + kmax * sizeof(rmx_desc)),
+                                                     halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc)),
                                dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>()),
                    ctx_, "rmx_kpm_seq");
       remap::check(rmx_frc_scan(ctx_, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0,
                                 carry_pos, &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
                    ctx_, "rmx_frc_scan");
-      std::uint32_t maxk = 0;
-      remap::check(rmx_kpe_status(ctx_, &maxk), ctx_, "rmx_kpe_status");
+      const int kst = rmx_kpe_status(ctx_, &maxk);
+      if (kst == RMX_ERR_KMAX && maxk <= max_kmax) {  // larger tables, same block again
+        (void)rmx_kpm_status(ctx_, nullptr);          // (its flags belong to the truncated tables)
+        grow_tables(maxk, !first);
+        carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
+        continue;
+      }
+      remap::check(kst, ctx_, "rmx_kpe_status");
       remap::check(rmx_kpm_status(ctx_, nullptr), ctx_, "rmx_kpm_status");
+      break;
+      }
       // the last table is the next block's halo
-      remap::check(rmx_copy(ctx_, halo_.get(), desc_.get<rmx_desc>() + std::size_t(n - 1) * kmax, kmax * sizeof(rmx_desc)),
+      remap::check(rmx_copy(ctx_, halo_.get(), desc_.get<rmx_desc>() + std::size_t(n - 1) * kmax_, kmax_ * sizeof(rmx_desc)),
                    ctx_, "rmx_copy");
-      remap::check(rmx_copy(ctx_, halo_.get<std::uint8_t>() + kmax * sizeof(rmx_desc), kcount_.get<std::uint32_t>() + (n - 1), 4),
+      remap::check(rmx_copy(ctx_, halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc), kcount_.get<std::uint32_t>() + (n - 1), 4),
                    ctx_, "rmx_copy");
       clk.mark("device: kpe + kpm + scan");
       // ---- results to the host ----
@@ -258,13 +286,13 @@ public:
       h_frag_.resize(n);
       h_k_.resize(n);
       h_med_.reserve(ctx_, std::size_t(n) * area);
-      const std::uint32_t tstride = std::max<std::uint32_t>(1, std::min(maxk, kmax));  // rows actually used
+      const std::uint32_t tstride = std::max<std::uint32_t>(1, std::min(maxk, kmax_));  // rows actually used
       h_tab_.resize(std::size_t(n) * tstride);
       remap::check(rmx_download(ctx_, h_pos_.data(), pos_.get(), 8 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_frag_.data(), frag_.get(), 4 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_k_.data(), kcount_.get(), 4 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_med_.get(), median_.get(), n * area), ctx_, "rmx_download");
-      remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax * sizeof(rmx_desc),
+      remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax_ * sizeof(rmx_desc),
                                    tstride * sizeof(rmx_desc), n),
                    ctx_, "rmx_download_2d");
       clk.mark("downloads");
@@ -316,16 +344,24 @@ public:
       for (std::uint32_t i = 0; i < n;) {
         std::uint32_t j = i;
         while (j < n && h_frag_[j] == h_frag_[i]) ++j;
-        if (fragments_.empty() || h_frag_[i] != current_id_) add_fragment(h_frag_[i]);
-        // grow the canvas once for the whole run, then one batched blit
-        for (std::uint32_t t = i; t < j; ++t) current_->ensure({h_pos_[2 * t], h_pos_[2 * t + 1]}, dim_);
-        remap::check(rmx_fgm_blit_batch(ctx_, frames_.get<std::uint8_t>() + i * area, pos_.get<std::int32_t>() + 2 * i,
-                                        nullptr, 0, j - i, current_->device_canvas(),
-                                        std::uint32_t(current_->dim_.width_), std::uint32_t(current_->dim_.height_),
-                                        current_->zero_.x_, current_->zero_.y_),
-                     ctx_, "rmx_fgm_blit_batch");
+        if (fresh || fragments_.empty() || h_frag_[i] != current_id_) add_fragment(h_frag_[i]);
+        fresh = false;
+        auto blit_run = [&](std::uint32_t a, std::uint32_t b) {
+          // grow the canvas once for the whole run, then one batched blit
+          for (std::uint32_t t = a; t < b; ++t) current_->ensure({h_pos_[2 * t], h_pos_[2 * t + 1]}, dim_);
+          remap::check(rmx_fgm_blit_batch(ctx_, frames_.get<std::uint8_t>() + a * area, pos_.get<std::int32_t>() + 2 * a,
+                                          nullptr, 0, b - a, current_->device_canvas(),
+                                          std::uint32_t(current_->dim_.width_), std::uint32_t(current_->dim_.height_),
+                                          current_->zero_.x_, current_->zero_.y_),
+                       ctx_, "rmx_fgm_blit_batch");
+        };
+        if (!exact_callbacks_) blit_run(i, j);
         // ---- replay: bookkeeping + callback per frame, in order (frc.hpp:117-119) ----
         for (std::uint32_t t = i; t < j; ++t) {
+          if (exact_callbacks_) {  // the callback sees the canvas exactly after frame t
+            blit_run(t, t + 1);
+            remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
+          }
           image_type const& median = *medians[t];
           fgm::point_t p{h_pos_[2 * t], h_pos_[2 * t + 1]};
           if constexpr (device_codec)
@@ -357,8 +393,28 @@ private:
     current_ = &fragments_.emplace_back(dim_);
     current_id_ = id;
   }
+  // A frame had `need` keypoints: switch to a context whose tables hold them (power of two,
+  // at most max_kmax); the halo table moves to the new stride.
+  void grow_tables(std::uint32_t need, bool have_halo) {
+    std::uint32_t k = kmax_;
+    while (k < need) k <<= 1;
+    k = std::min(k, max_kmax);
+    rmx_ctx* c = remap::context_cache::get(std::uint32_t(dim_.width_), std::uint32_t(dim_.height_), 4, 2, 16, k);
+    remap::device_buffer halo{c, k * sizeof(rmx_desc) + 16};
+    if (have_halo) {
+      remap::check(rmx_copy(c, halo.get(), halo_.get(), kmax_ * sizeof(rmx_desc)), c, "rmx_copy");
+      remap::check(rmx_copy(c, halo.get<std::uint8_t>() + k * sizeof(rmx_desc),
+                            halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc), 4),
+                   c, "rmx_copy");
+      remap::check(rmx_sync(c), c, "rmx_sync");
+    }
+    halo_ = std::move(halo);
+    ctx_ = c;
+    kmax_ = k;
+  }
   void reserve(std::uint32_t n) {
     const std::size_t area = dim_.area();
+    const std::uint32_t kmax = kmax_;
     frames_.reserve(ctx_, n * area);
     median_.reserve(ctx_, n * area);
     desc_.reserve(ctx_, std::size_t(n) * kmax * sizeof(rmx_desc));
@@ -372,6 +428,8 @@ private:
 
   mrl::dimensions_t dim_;
   rmx_ctx* ctx_;
+  std::uint32_t kmax_{kmax};
+  bool exact_callbacks_{false};
   remap::device_buffer frames_, median_, desc_, kcount_, dxdy_, matched_, pos_, frag_, halo_;
   std::vector<std::int32_t> h_pos_;
   std::vector<std::uint32_t> h_frag_, h_k_;

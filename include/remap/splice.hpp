@@ -24,7 +24,13 @@ namespace fgs {
 
 namespace details {
 
+// rows of a snippet's descriptor table: extract_single starts with snippet_kmax and, when a
+// canvas has more keypoints (rmx_kpe_status reports how many), extracts again with the next
+// power of two, up to snippet_kmax_limit = what rmx_kpm_cell_pairs takes per fragment.  The
+// reference has no limit (kpr.hpp:121-124); beyond 4096 keypoints per fragment splice throws
+// remap::device_error(RMX_ERR_KMAX) — INTEGRATION.md §4.
 inline constexpr std::uint32_t snippet_kmax = 2048;
+inline constexpr std::uint32_t snippet_kmax_limit = 4096;
 inline constexpr kpm::cell_size_t cell_size{15, 15};  // fgs.hpp:121
 
 struct snippet;
@@ -40,7 +46,7 @@ struct delta {
 struct snippet {
   fgm::fragment fragment_;
   remap::device_buffer mask_;   // dim.area() bytes, non-zero where the canvas has content
-  remap::device_buffer table_;  // snippet_kmax rmx_desc rows
+  remap::device_buffer table_;  // count_ rmx_desc rows (stride: the kmax it was extracted with)
   std::uint32_t count_{0};
   std::list<delta> edges_;
 };
@@ -49,23 +55,38 @@ struct snippet {
 inline snippet extract_single(fgm::fragment&& fragment) {
   snippet s{std::move(fragment), {}, {}, 0, {}};
   const auto dim = s.fragment_.dimensions();
-  rmx_ctx* c = remap::context_cache::get(std::uint32_t(dim.width_), std::uint32_t(dim.height_), 1, 1, 0, snippet_kmax);
+  const std::uint32_t w = std::uint32_t(dim.width_), h = std::uint32_t(dim.height_);
+  rmx_ctx* c = remap::context_cache::get(w, h, 1, 1, 0, snippet_kmax);
   const std::size_t area = dim.area();
   remap::device_buffer image{c, area}, median{c, area}, kcount{c, 16};
   s.mask_ = remap::device_buffer{c, area};
-  s.table_ = remap::device_buffer{c, snippet_kmax * sizeof(rmx_desc)};
   if (s.fragment_.device_canvas()) {
-    remap::check(rmx_fgm_blend(c, s.fragment_.device_canvas(), std::uint32_t(dim.width_), std::uint32_t(dim.height_),
-                               image.get<std::uint8_t>(), s.mask_.get<std::uint8_t>()),
+    remap::check(rmx_fgm_blend(c, s.fragment_.device_canvas(), w, h, image.get<std::uint8_t>(), s.mask_.get<std::uint8_t>()),
                  c, "rmx_fgm_blend");
   } else {
     remap::check(rmx_memset(c, image.get(), 0, area), c, "rmx_memset");
     remap::check(rmx_memset(c, s.mask_.get(), 0, area), c, "rmx_memset");
   }
-  remap::check(rmx_kpe_batch(c, image.get<std::uint8_t>(), 1, median.get<std::uint8_t>(), s.table_.get<rmx_desc>(),
-                             kcount.get<std::uint32_t>()),
-               c, "rmx_kpe_batch");
-  remap::check(rmx_kpe_status(c, nullptr), c, "rmx_kpe_status");
+  for (std::uint32_t kmax = snippet_kmax;;) {
+    s.table_ = remap::device_buffer{c, kmax * sizeof(rmx_desc)};
+    remap::check(rmx_kpe_batch(c, image.get<std::uint8_t>(), 1, median.get<std::uint8_t>(), s.table_.get<rmx_desc>(),
+                               kcount.get<std::uint32_t>()),
+                 c, "rmx_kpe_batch");
+    std::uint32_t need = 0;
+    const int st = rmx_kpe_status(c, &need);
+    if (st == RMX_ERR_KMAX && need <= snippet_kmax_limit) {  // same canvas, larger table
+      while (kmax < need) kmax <<= 1;
+      remap::check(rmx_sync(c), c, "rmx_sync");
+      c = remap::context_cache::get(w, h, 1, 1, 0, kmax);
+      continue;
+    }
+    if (st == RMX_ERR_KMAX)
+      throw remap::device_error(st, "fgs::splice: a fragment of " + std::to_string(w) + "x" + std::to_string(h) + " has " +
+                                        std::to_string(need) + " keypoints; rmx_kpm_cell_pairs takes at most " +
+                                        std::to_string(snippet_kmax_limit) + " per fragment");
+    remap::check(st, c, "rmx_kpe_status");
+    break;
+  }
   remap::check(rmx_download(c, &s.count_, kcount.get(), 4), c, "rmx_download");
   return s;
 }
@@ -92,7 +113,7 @@ void match_partial(It head, It first, It last) {
     pairs.push_back(0);
     pairs.push_back(std::uint32_t(i + 1));
   }
-  rmx_ctx* c = remap::context_cache::get(16, 8, 1, 1, 0, snippet_kmax);
+  rmx_ctx* c = remap::context_cache::get(16, 8, 1, 1, 0, snippet_kmax_limit);
   std::vector<rmx_vote> votes(others.size());
   remap::check(rmx_kpm_cell_pairs(c, tables.data(), counts.data(), masks.data(), dims.data(),
                                   std::uint32_t(tables.size()), pairs.data(), std::uint32_t(others.size()),

@@ -13,6 +13,7 @@
 
 #include "common.h"
 #include "kpe.hip"
+#include "kpe_fused.hip"
 #include "table.hip"
 #include "kpm.hip"
 #include "kpm_cell.hip"
@@ -35,6 +36,11 @@ struct rmx_ctx {
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
+  // launch shape of kpe_fused for this context's frames (plan_fused); ok = false: kpe_main + kpe_finish
+  struct FusedPlan {
+    bool ok = false, v16 = false;
+    uint32_t R = 0, nt = 0, fpb = 0, pitch = 0, lds = 0;
+  } fused;
   uint32_t overlap_subs = 0;    // RMX_OVERLAP: finish of sub-batch i on a second stream beside main of i + 1
   hipStream_t aux = nullptr;
   std::vector<hipEvent_t> ev_main, ev_fin;
@@ -93,6 +99,60 @@ Bands make_bands(uint32_t W, uint32_t H, uint32_t gw, uint32_t gh, uint32_t ov) 
   return b;
 }
 
+// Tile shape of kpe_fused: NT threads = FPB frames x Wd dword columns (the multiple of 64 that
+// leaves fewest idle lanes), R output rows, key tiles padded so that the lanes of a wave keep
+// hitting consecutive LDS banks across the seam between two frames of the workgroup.
+rmx_ctx::FusedPlan plan_fused(uint32_t W, uint32_t H) {
+  rmx_ctx::FusedPlan pl;
+  // opt-in (experiments): measured slower than kpe_main + kpe_finish, DESIGN.md §4.1c
+  if (W % 4 != 0 || !getenv("RMX_KPE_FUSED")) return pl;
+  const uint32_t Wd = W / 4;
+  if (Wd > 1024) return pl;
+  uint32_t best_nt = 0;
+  double best_waste = 2.0;
+  for (uint32_t nt = 256; nt <= 1024; nt += 64) {
+    if (nt < Wd) continue;
+    const uint32_t fpb = std::min(nt / Wd, 32u);
+    const double waste = 1.0 - (double)(fpb * Wd) / nt;
+    if (waste < best_waste - 1e-9) best_waste = waste, best_nt = nt;  // ties: the smaller workgroup
+  }
+  if (!best_nt) return pl;
+  uint32_t R = 16;
+  if (const char* e = getenv("RMX_KPE_R")) R = (uint32_t)atoi(e);
+  if (R != 8 && R != 16 && R != 24) R = 16;
+  for (;; R -= 8) {
+    const uint32_t TR = R + 4, fpb = std::min(best_nt / Wd, 32u);
+    uint32_t padw = (32 - ((TR - 1) * Wd) % 32) % 32;  // (TR * Wd + padw) == Wd (mod 32 banks)
+    padw = (padw + 3) & ~3u;
+    const uint32_t pitch = (TR * Wd + padw) * 4;
+    const uint32_t lds = kf_lds_bytes(fpb, pitch);
+    if (lds <= 160 * 1024) {
+      pl.ok = true;
+      pl.v16 = W % 16 == 0;
+      pl.R = R;
+      pl.nt = best_nt;
+      pl.fpb = fpb;
+      pl.pitch = pitch;
+      pl.lds = lds;
+      return pl;
+    }
+    if (R == 8) return pl;
+  }
+}
+
+template <int R, bool V16>
+hipError_t launch_fused(const rmx_ctx::FusedPlan& pl, const KpeFusedParams& kp, hipStream_t stream) {
+  static uint32_t lds_set = 0;  // dynamic LDS above the 64-KB default needs the attribute once per size
+  if (pl.lds > 64 * 1024 && pl.lds > lds_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kpe_fused<R, V16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
+    if (e != hipSuccess) return e;
+    lds_set = pl.lds;
+  }
+  const uint32_t groups = (kp.n + pl.fpb - 1) / pl.fpb;
+  hipLaunchKernelGGL((kpe_fused<R, V16>), dim3(groups * kp.strips), dim3(pl.nt), pl.lds, stream, kp);
+  return hipGetLastError();
+}
+
 int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   if (n <= ctx->n_cap) return RMX_OK;
   if (ctx->raw) (void)hipFree(ctx->raw);
@@ -104,7 +164,7 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   ctx->tflag = nullptr;
   ctx->cand = nullptr;
   ctx->n_cap = 0;
-  const size_t cand_bytes = (size_t)n * ((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * sizeof(uint32_t);
+  const size_t cand_bytes = ctx->fused.ok ? 256 : (size_t)n * ((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * sizeof(uint32_t);
   RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
   RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->tflag, (size_t)n * sizeof(uint32_t)));
@@ -198,6 +258,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   ctx->overlap = overlap;
   ctx->kmax = kmax;
   ctx->bands = make_bands(width, height, grid_w, grid_h, overlap);
+  ctx->fused = plan_fused(width, height);
   if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("RMX_OVERLAP")) ctx->overlap_subs = (uint32_t)std::max(0, atoi(e));
   if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
@@ -415,7 +476,35 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     }
   }
   uint32_t sub_idx = 0;
-  for (uint32_t f0 = 0; f0 < n; f0 += sub, ++sub_idx) {
+  if (ctx->fused.ok) {
+    const rmx_ctx::FusedPlan& pl = ctx->fused;
+    KpeFusedParams kp{};
+    kp.frames = frames;
+    kp.median = median;
+    kp.raw = ctx->raw;
+    kp.kcount = ctx->kraw;
+    kp.status = ctx->status;
+    kp.n = n;
+    kp.W = ctx->W;
+    kp.H = ctx->H;
+    kp.Wd = ctx->W / 4;
+    kp.kmax = ctx->kmax;
+    kp.fpb = pl.fpb;
+    kp.strips = (ctx->H + pl.R - 1) / pl.R;
+    kp.pitch = pl.pitch;
+    hipError_t e;
+    {
+      Timer t(ctx, &ctx->ms_kpe);
+      if (pl.R == 8)
+        e = pl.v16 ? launch_fused<8, true>(pl, kp, ctx->stream) : launch_fused<8, false>(pl, kp, ctx->stream);
+      else if (pl.R == 24)
+        e = pl.v16 ? launch_fused<24, true>(pl, kp, ctx->stream) : launch_fused<24, false>(pl, kp, ctx->stream);
+      else
+        e = pl.v16 ? launch_fused<16, true>(pl, kp, ctx->stream) : launch_fused<16, false>(pl, kp, ctx->stream);
+    }
+    RMX_HIP(e);
+  }
+  for (uint32_t f0 = 0; !ctx->fused.ok && f0 < n; f0 += sub, ++sub_idx) {
     const uint32_t m = std::min(sub, n - f0);
     KpeParams p{};
     p.frames = frames + (size_t)f0 * ctx->W * ctx->H;
@@ -485,6 +574,13 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     tp.wave_ok = ctx->W <= 1024 && ctx->H <= 1024 && ctx->kmax <= 2048;
     tp.left = ctx->tflag;
     hipLaunchKernelGGL(kpe_table, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, tp);
+    // frames too big for the rank bitmap sort 64-bit keys in LDS: 128 KB at kmax = 16 384, above
+    // the 64 KB a launch gets without the attribute
+    static size_t lds_allowed = 64 * 1024;
+    if (lds > lds_allowed) {
+      RMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kpe_table_rest), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      lds_allowed = lds;
+    }
     hipLaunchKernelGGL(kpe_table_rest, dim3(std::min(n, 4096u)), dim3(256), lds, ctx->stream, tp);
   }
   RMX_HIP(hipGetLastError());

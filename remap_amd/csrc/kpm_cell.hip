@@ -63,56 +63,6 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
   const uint32_t* p_pts = P + kpm_off_pts(p.kmax);
   const uint32_t pmaskh = P[H_HTMASK];
 
-  // ---- a. shared codes in the current map's iteration order (kpm.hpp:257-261) ----
-  uint32_t nm = 0, total = 0;
-  bool overflow = false;
-  for (uint32_t base = 0; base < Gc; base += 64) {
-    uint32_t pairs = 0, gp = 0, gc = 0;
-    if (base + lane < Gc) {
-      gc = c_giter[base + lane];
-      uint32_t c[4];
-      load_code(cdesc + c_gfirst[gc], c);
-      uint32_t s = fnv_code_lo(c) & pmaskh;
-      for (;;) {
-        uint32_t v = p_ht[s];
-        if (v == 0) break;
-        uint32_t c2[4];
-        load_code(pdesc + p_gfirst[v - 1], c2);
-        if (same_code(c, c2)) {
-          gp = v - 1;
-          pairs = (p_gstart[gp + 1] - p_gstart[gp]) * (c_gstart[gc + 1] - c_gstart[gc]);
-          break;
-        }
-        s = (s + 1) & pmaskh;
-      }
-    }
-    uint64_t bal = __builtin_amdgcn_ballot_w64(pairs != 0);
-    uint32_t incl = pairs;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      uint32_t t = (uint32_t)__shfl_up((int)incl, o);
-      if (lane >= (uint32_t)o) incl += t;
-    }
-    uint32_t cnt = (uint32_t)__builtin_popcountll(bal);
-    if (nm + cnt > KC_MG) {
-      overflow = true;
-      break;
-    }
-    if (pairs != 0) {
-      uint32_t at = nm + mbcnt(bal);
-      mg_p[at] = gp;
-      mg_c[at] = gc;
-      mg_base[at] = total + incl - pairs;
-    }
-    total += (uint32_t)__shfl((int)incl, 63);
-    nm += cnt;
-  }
-  if (overflow) {
-    if (lane == 0) atomicOr(&p.status[1], 8u);
-    return;
-  }
-  if (nm == 0) return;  // offsets.empty() -> nullopt (kpm.hpp:380-382)
-  if (lane == 0) mg_base[nm] = total;
   for (uint32_t s = lane; s < KC_HS; s += 64) {
     hk[s] = 0;
     hc[s] = 0;
@@ -123,55 +73,109 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __builtin_amdgcn_wave_barrier();
 
-  // ---- b. votes per offset and distinct cells per offset ----
-  uint32_t my_new = 0, my_fail = 0;
-  for (uint32_t t = lane; t < total; t += 64) {
-    uint32_t lo = 0, hi = nm;
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (mg_base[mid] <= t)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    uint32_t gp = mg_p[lo], gc = mg_c[lo], rel = t - mg_base[lo];
-    uint32_t cs = c_gstart[gc], nc = c_gstart[gc + 1] - cs;
-    uint32_t ip = rel / nc, ic = rel - ip * nc;
-    uint32_t pp = p_pts[p_gstart[gp] + ip], cp = c_pts[cs + ic];
-    int32_t px = (int32_t)(pp & 0xffffu), py = (int32_t)(pp >> 16), cx = (int32_t)(cp & 0xffffu), cy = (int32_t)(cp >> 16);
-    uint32_t key = off_key(px - cx, py - cy);
-    uint32_t cellk = (uint32_t)(min(px, cx) / (int32_t)p.cell_w) << 12 | (uint32_t)(min(py, cy) / (int32_t)p.cell_h);
-    uint32_t s = (key * 2654435761u) >> 21;
-    bool placed = false;
-    for (uint32_t probes = 0; probes <= KC_HS; ++probes) {
-      uint32_t v = atomicCAS(&hk[s], 0u, key);
-      if (v == 0u) ++my_new;
-      if (v == 0u || v == key) {
-        atomicAdd(&hc[s], 1u);
-        atomicMin(&hs[s], t);
-        placed = true;
-        break;
+  // The current map's codes are walked in its iteration order, KC_MG codes at a time: (a) the
+  // shared ones of the chunk with their pair counts, (b) the votes of their point pairs.  The
+  // pair index t (first touch of an offset = its insertion into the totalizator) runs on
+  // across chunks, so a fragment may share any number of codes with the other one.
+  uint32_t my_new = 0, my_fail = 0, pairs_before = 0;
+  for (uint32_t cb = 0; cb < Gc; cb += KC_MG) {
+    const uint32_t ce = min(Gc, cb + KC_MG);
+    // ---- a. shared codes in the current map's iteration order (kpm.hpp:257-261) ----
+    uint32_t nm = 0, total = 0;
+    for (uint32_t base = cb; base < ce; base += 64) {
+      uint32_t pairs = 0, gp = 0, gc = 0;
+      if (base + lane < ce) {
+        gc = c_giter[base + lane];
+        uint32_t c[4];
+        load_code(cdesc + c_gfirst[gc], c);
+        uint32_t s = fnv_code_lo(c) & pmaskh;
+        for (;;) {
+          uint32_t v = p_ht[s];
+          if (v == 0) break;
+          uint32_t c2[4];
+          load_code(pdesc + p_gfirst[v - 1], c2);
+          if (same_code(c, c2)) {
+            gp = v - 1;
+            pairs = (p_gstart[gp + 1] - p_gstart[gp]) * (c_gstart[gc + 1] - c_gstart[gc]);
+            break;
+          }
+          s = (s + 1) & pmaskh;
+        }
       }
-      s = (s + 1) & (KC_HS - 1);
-    }
-    if (!placed) {
-      ++my_fail;
-      continue;
-    }
-    unsigned long long k64 = (unsigned long long)(s + 1) << 32 | cellk;
-    uint32_t h = (uint32_t)((k64 * 0x9E3779B97F4A7C15ull) >> 51);  // 13 bits
-    bool done = false;
-    for (uint32_t probes = 0; probes <= KC_PS; ++probes) {
-      unsigned long long v = atomicCAS(&pc[h], 0ull, k64);
-      if (v == 0ull) atomicAdd(&hcell[s], 1u);
-      if (v == 0ull || v == k64) {
-        done = true;
-        break;
+      uint64_t bal = __builtin_amdgcn_ballot_w64(pairs != 0);
+      uint32_t incl = pairs;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+        if (lane >= (uint32_t)o) incl += t;
       }
-      h = (h + 1) & (KC_PS - 1);
+      if (pairs != 0) {
+        uint32_t at = nm + mbcnt(bal);
+        mg_p[at] = gp;
+        mg_c[at] = gc;
+        mg_base[at] = total + incl - pairs;
+      }
+      total += (uint32_t)__shfl((int)incl, 63);
+      nm += (uint32_t)__builtin_popcountll(bal);
     }
-    if (!done) ++my_fail;
+    if (nm == 0) continue;
+    if (lane == 0) mg_base[nm] = total;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    // ---- b. votes per offset and distinct cells per offset ----
+    for (uint32_t t = lane; t < total; t += 64) {
+      uint32_t lo = 0, hi = nm;
+      while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (mg_base[mid] <= t)
+          lo = mid;
+        else
+          hi = mid;
+      }
+      uint32_t gp = mg_p[lo], gc = mg_c[lo], rel = t - mg_base[lo];
+      uint32_t cs = c_gstart[gc], nc = c_gstart[gc + 1] - cs;
+      uint32_t ip = rel / nc, ic = rel - ip * nc;
+      uint32_t pp = p_pts[p_gstart[gp] + ip], cp = c_pts[cs + ic];
+      int32_t px = (int32_t)(pp & 0xffffu), py = (int32_t)(pp >> 16), cx = (int32_t)(cp & 0xffffu), cy = (int32_t)(cp >> 16);
+      uint32_t key = off_key(px - cx, py - cy);
+      uint32_t cellk = (uint32_t)(min(px, cx) / (int32_t)p.cell_w) << 12 | (uint32_t)(min(py, cy) / (int32_t)p.cell_h);
+      uint32_t s = (key * 2654435761u) >> 21;
+      bool placed = false;
+      for (uint32_t probes = 0; probes <= KC_HS; ++probes) {
+        uint32_t v = atomicCAS(&hk[s], 0u, key);
+        if (v == 0u) ++my_new;
+        if (v == 0u || v == key) {
+          atomicAdd(&hc[s], 1u);
+          atomicMin(&hs[s], pairs_before + t);
+          placed = true;
+          break;
+        }
+        s = (s + 1) & (KC_HS - 1);
+      }
+      if (!placed) {
+        ++my_fail;
+        continue;
+      }
+      unsigned long long k64 = (unsigned long long)(s + 1) << 32 | cellk;
+      uint32_t h = (uint32_t)((k64 * 0x9E3779B97F4A7C15ull) >> 51);  // 13 bits
+      bool done = false;
+      for (uint32_t probes = 0; probes <= KC_PS; ++probes) {
+        unsigned long long v = atomicCAS(&pc[h], 0ull, k64);
+        if (v == 0ull) atomicAdd(&hcell[s], 1u);
+        if (v == 0ull || v == k64) {
+          done = true;
+          break;
+        }
+        h = (h + 1) & (KC_PS - 1);
+      }
+      if (!done) ++my_fail;
+    }
+    pairs_before += total;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // the chunk's lists are free again
   }
+  if (pairs_before == 0) return;  // offsets.empty() -> nullopt (kpm.hpp:380-382)
   uint32_t D = my_new, F = my_fail;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {

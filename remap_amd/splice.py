@@ -13,7 +13,12 @@ import numpy as np
 from . import lib as L
 
 CELL = (15, 15)  # fgs.hpp:121
+# Rows of a snippet's descriptor table: extraction starts with SNIPPET_KMAX and is repeated with
+# the next power of two when a canvas has more keypoints, up to SNIPPET_KMAX_LIMIT = what
+# rmx_kpm_cell_pairs takes per fragment (the reference has no limit; beyond it splice raises
+# RemapError(RMX_ERR_KMAX)).
 SNIPPET_KMAX = 2048
+SNIPPET_KMAX_LIMIT = 4096
 
 
 class Fragment:
@@ -100,12 +105,20 @@ def _extract_single(ctx_cache, frag, device):  # fgs.hpp:80-89
     any_ctx = ctx_cache("any")
     img, mask = any_ctx.fgm_blend(frag.canvas)
     w, h = frag.dims
-    kctx = ctx_cache((w, h))
-    _, desc, kc = kctx.kpe(img[None].contiguous())
-    rc, maxk = kctx.kpe_status()
-    if rc:
-        raise L.RemapError(rc, "rmx_kpe_status", f"snippet has {maxk} keypoints > {SNIPPET_KMAX}")
-    return _Snippet(frag, mask, desc[0], int(kc[0].item()))
+    kmax = SNIPPET_KMAX
+    while True:
+        kctx = ctx_cache((w, h, kmax))
+        _, desc, kc = kctx.kpe(img[None].contiguous())
+        rc, maxk = kctx.kpe_status()
+        if rc == L.RMX_ERR_KMAX and maxk <= SNIPPET_KMAX_LIMIT:  # same canvas, larger table
+            while kmax < maxk:
+                kmax *= 2
+            continue
+        if rc:
+            raise L.RemapError(rc, "rmx_kpe_status",
+                               f"a fragment of {w}x{h} has {maxk} keypoints; rmx_kpm_cell_pairs takes at most "
+                               f"{SNIPPET_KMAX_LIMIT} per fragment")
+        return _Snippet(frag, mask, desc[0], int(kc[0].item()))
 
 
 def splice(fragments, device=0, dist=None, group=None):
@@ -120,8 +133,8 @@ def splice(fragments, device=0, dist=None, group=None):
 
     def ctx_cache(key):
         if key not in ctxs:
-            w, h = (16, 8) if key == "any" else key
-            ctxs[key] = L.Context(w, h, grid=(1, 1), overlap=0, kmax=SNIPPET_KMAX, device=device)
+            w, h, kmax = (16, 8, SNIPPET_KMAX_LIMIT) if key == "any" else key
+            ctxs[key] = L.Context(w, h, grid=(1, 1), overlap=0, kmax=kmax, device=device)
         return ctxs[key]
 
     mctx = ctx_cache("any")

@@ -177,6 +177,39 @@ static int run_time(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob
   return 0;
 }
 
+// two collect() calls on ONE collector (frc.hpp:55-68 starts each with process_init, which always
+// opens a fragment): the second stream must not be blitted into the first one's last fragment
+static int run_twice(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob) {
+  frc::collector collector{dim};
+  std::size_t calls = 0;
+  auto cb = [&](fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) { ++calls; };
+  collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+  collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+  auto fragments = collector.complete();
+  std::printf("calls %zu nfrag %zu\n", calls, fragments.size());
+  std::size_t fi = 0;
+  for (auto& f : fragments)
+    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu\n", fi++, f.dimensions().width_,
+                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), canvas_sum(f));
+  return 0;
+}
+
+// exact_callbacks(true): the callback of frame t sees the fragment exactly after frame t
+// (frc.hpp:117-119) — prints the canvas checksum it saw
+static int run_exact(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob) {
+  frc::collector collector{dim};
+  collector.exact_callbacks(true);
+  auto cb = [&](fgm::fragment const& fragment, frc::frame_type const& frame, frc::image_type const&, frc::grid_type const&) {
+    std::printf("seen %zu frames %zu dims %zu %zu zero %d %d sum %llu\n", frame.number_, fragment.frames().size(),
+                fragment.dimensions().width_, fragment.dimensions().height_, fragment.zero().x_, fragment.zero().y_,
+                canvas_sum(fragment));
+  };
+  collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+  auto fragments = collector.complete();
+  std::printf("nfrag %zu\n", fragments.size());
+  return 0;
+}
+
 // the constants of frc::collector::match_config (frc.hpp:30-44)
 struct seq_cfg {
   using allocator_type = std::allocator<char>;
@@ -197,6 +230,8 @@ int main(int argc, char** argv) {
   if (argc > 4 && std::string(argv[4]) == "fdf") return run_fdf(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "time") return run_time(dim, blob, false);
   if (argc > 4 && std::string(argv[4]) == "timenic") return run_time(dim, blob, true);
+  if (argc > 4 && std::string(argv[4]) == "twice") return run_twice(dim, blob);
+  if (argc > 4 && std::string(argv[4]) == "exact") return run_exact(dim, blob);
 
   frc::collector collector{dim};
   std::size_t calls = 0, entries = 0, last_no = 0;

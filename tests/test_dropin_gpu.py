@@ -32,6 +32,35 @@ def test_collector_drop_in_matches_oracle(gpu, tmp_path):
     frames, truth = scroller_v1(100, dens=100)
     frames = frames.copy()
     frames[40] = 6  # a fragment break
+    check_collect(exe, frames, tmp_path)
+
+
+def noisy(p, seed):
+    rng = np.random.default_rng(seed)
+    img = np.full((240, 320), 6, np.uint8)
+    m = rng.random(img.shape) < p
+    img[m] = rng.integers(0, 16, int(m.sum()))
+    return img
+
+
+def test_collector_grows_tables_beyond_kmax(gpu, tmp_path):
+    """Frames with more keypoints than the collector's initial table stride (2 048 rows): the
+    block is run again with larger tables, results equal the oracle's (the reference has no
+    limit).  Two such frames follow each other, one a shifted copy of the other, so the dense
+    matcher tiers see them too; the second block of the stream starts with one (halo at the
+    new stride)."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(40, dens=100)
+    frames = frames.copy()
+    big = noisy(0.25, 5)
+    assert O.orc_kpe(big)[2] > 2048
+    frames[12] = big
+    frames[13] = np.roll(big, -2, axis=1)
+    frames[14] = np.roll(big, -3, axis=1)
+    check_collect(exe, frames, tmp_path)
+
+
+def check_collect(exe, frames, tmp_path):
     blob = tmp_path / "frames.bin"
     frames.tofile(blob)
     out = subprocess.run([exe, str(blob), "320", "240"], check=True, capture_output=True, text=True).stdout
@@ -73,6 +102,62 @@ def test_collector_drop_in_matches_oracle(gpu, tmp_path):
     d0 = O.orc_kpe(frames[0])[1]
     assert int(pair[2]) == sum(bin(int(x)).count("1") for x in d0["region_mask"])
     assert int(pair[4]) == m and (int(pair[6]), int(pair[7])) == d
+
+
+def oracle_fragments(frames):
+    """canvases (poly_sum), dims and frame counts of the oracle's collect over `frames`"""
+    o = O.orc_frc(frames)
+    res = []
+    for f in range(int(o["frag"].max()) + 1):
+        sel = o["frag"] == f
+        cw, ch, zx, zy = O.orc_fgm_extent(o["pos"][sel], 320, 240)
+        can = np.zeros((ch, cw, 16), np.uint16)
+        for i in np.nonzero(sel)[0]:
+            O.orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
+        res.append((cw, ch, int(sel.sum()), poly_sum(can)))
+    return o, res
+
+
+def test_second_collect_opens_a_new_fragment(gpu, tmp_path):
+    """collect() twice on one collector: process_init opens a fragment both times
+    (frc.hpp:83-95); the second stream must not land in the first one's canvas."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(20, dens=100)  # one fragment per pass
+    blob = tmp_path / "frames.bin"
+    frames.tofile(blob)
+    out = subprocess.run([exe, str(blob), "320", "240", "twice"], check=True, capture_output=True, text=True).stdout
+    lines = [l.split() for l in out.strip().splitlines()]
+    _, want = oracle_fragments(frames)
+    assert len(want) == 1
+    assert int(lines[0][1]) == 2 * (len(frames) - 1) and int(lines[0][3]) == 2
+    for fl in lines[1:]:
+        cw, ch, nf, s = want[0]
+        assert [int(fl[3]), int(fl[4]), int(fl[9]), int(fl[11])] == [cw, ch, nf, s]
+
+
+def test_exact_callbacks_see_the_canvas_after_their_frame(gpu, tmp_path):
+    """exact_callbacks(true): the fragment passed to the callback of frame t holds exactly the
+    frames up to t (frc.hpp:117-119) — canvas extent and bins included."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(24, dens=100)
+    frames = frames.copy()
+    frames[9] = 6  # a fragment break
+    blob = tmp_path / "frames.bin"
+    frames.tofile(blob)
+    out = subprocess.run([exe, str(blob), "320", "240", "exact"], check=True, capture_output=True, text=True).stdout
+    seen = {int(l.split()[1]): l.split() for l in out.strip().splitlines() if l.startswith("seen ")}
+    o = O.orc_frc(frames)
+    assert sorted(seen) == list(range(1, len(frames)))
+    for t in range(1, len(frames)):
+        f = o["frag"][t]
+        idx = [i for i in range(t + 1) if o["frag"][i] == f]
+        cw, ch, zx, zy = O.orc_fgm_extent(o["pos"][idx], 320, 240)
+        can = np.zeros((ch, cw, 16), np.uint16)
+        for i in idx:
+            O.orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
+        l = seen[t]
+        assert int(l[3]) == len(idx) and [int(l[5]), int(l[6])] == [cw, ch] and [int(l[8]), int(l[9])] == [zx, zy], t
+        assert int(l[11]) == poly_sum(can), t
 
 
 def test_builder_collect_splice_drop_in_matches_reference(gpu, tmp_path):
@@ -186,3 +271,44 @@ def test_fdf_filter_drop_in_matches_reference(gpu, tmp_path):
         for f, l in enumerate(frags):
             assert [int(l[3]), int(l[4])] == g[f"dims{k}"][f].tolist()
             assert int(l[11]) == int(g[f"canvas_sum{k}"][f]), (k, f)
+
+
+def test_splice_drop_in_fragments_beyond_2048_keypoints(gpu, tmp_path):
+    """fgs::splice through the drop-in headers with fragments whose blended canvases hold more
+    than 2 048 keypoints (the snippet tables' first size): extract_single extracts again with
+    larger tables.  Stream: a dense scroller run, a blank frame (fragment break), a second run
+    overlapping the first; the two runs must be spliced into one fragment whose canvas equals
+    the oracle's blits at the reported positions, the relative positions the oracle's offsets."""
+    exe = build_driver(str(tmp_path))
+    w, h = 320, 240
+    frames, _ = scroller_v1(150, dens=30)
+    a, b = frames[:110], frames[40:]  # 2 962 and 2 942 keypoints, 3 281 once merged
+    stream = np.concatenate([a, np.full((1, h, w), 6, np.uint8), b])
+    blob = tmp_path / "long.bin"
+    stream.tofile(blob)
+    out = subprocess.run([exe, str(blob), str(w), str(h), "splice"], check=True, capture_output=True, text=True).stdout
+    lines = out.strip().splitlines()
+    assert lines[0] == "collected 3" and lines[1] == "spliced 2", lines[:2]
+    frag_lines = [l.split() for l in lines if l.startswith("fragment ")]
+    frame_lines = [l.split() for l in lines if l.startswith("frame ")]
+    assert len(frame_lines) == len(stream)
+    by_frag = {}
+    for fl in frame_lines:
+        by_frag.setdefault(int(fl[3]), []).append((int(fl[1]), (int(fl[5]), int(fl[6]))))
+    merged = [k for k, v in by_frag.items() if len(v) == len(a) + len(b)]
+    assert len(merged) == 1
+    k = merged[0]
+    pos = dict(by_frag[k])
+    # relative positions inside each run = the oracle's; between the runs = the oracle's vote
+    oa, ob = O.orc_frc(a)["pos"], O.orc_frc(b)["pos"]
+    for i in range(len(a)):
+        assert tuple(np.array(pos[i]) - pos[0]) == tuple(oa[i] - oa[0])
+    base = len(a) + 1
+    for i in range(len(b)):
+        assert tuple(np.array(pos[base + i]) - pos[base]) == tuple(ob[i] - ob[0])
+    fl = frag_lines[k]
+    cw, ch = int(fl[3]), int(fl[4])
+    can = np.zeros((ch, cw, 16), np.uint16)
+    for no, p in pos.items():
+        O.orc_fgm_blit(can, (0, 0), stream[no], p)
+    assert int(fl[11]) == poly_sum(can)

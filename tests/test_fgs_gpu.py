@@ -74,3 +74,67 @@ def test_collect_then_splice_matches_reference(gpu):
         for no, p in f.frames:
             assert int(g["frag"][no]) == k and list(p) == g["pos"][no].tolist(), (k, no)
     al.close()
+
+
+def _collect_one(frames, w, h):
+    """one fragment out of a frame run: device Fragment + the oracle's canvas and positions"""
+    import torch
+
+    al = Aligner(w, h, kmax=4096)
+    out = al.align(torch.from_numpy(frames).cuda(), blit=True)
+    assert out["nfrag"] == 1
+    canvas, zero, _ = out["canvases"][0]
+    pos = out["pos"].cpu().numpy()
+    f = Fragment(canvas.clone(), zero, (w, h), [(i, pos[i]) for i in range(len(frames))])
+    f.normalize()
+    al.close()
+    o = O.orc_frc(frames)
+    cw, ch, zx, zy = O.orc_fgm_extent(o["pos"], w, h)
+    can = np.zeros((ch, cw, 16), np.uint16)
+    for i in range(len(frames)):
+        O.orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
+    assert np.array_equal(f.canvas.cpu().numpy().view(np.uint16), can)
+    return f, can, o["pos"] - [zx, zy]
+
+
+def test_splice_fragments_with_more_than_2048_keypoints(gpu):
+    """Two overlapping runs of a dense scroller: each fragment's blended canvas has between 2 048
+    and 4 096 keypoints, more than the snippet tables start with — extract_single repeats the
+    extraction with larger tables (the reference has no limit, kpr.hpp:121-124).  Vote, merged
+    canvas and frame positions equal what the oracle's pieces give."""
+    from remap_amd.synth import scroller_v1
+
+    w, h = 320, 240
+    frames, _ = scroller_v1(150, dens=30)
+    parts = [frames[:110], frames[40:]]  # 2 962 and 2 942 keypoints, 3 281 once merged
+    frags, cans, poss = zip(*[_collect_one(p, w, h) for p in parts])
+    descs, masks = [], []
+    for can in cans:
+        img, mask = O.orc_fgm_blend(can)
+        _, d, k = O.orc_kpe(img, 1, 1, 0)
+        assert 2048 < k <= 4096, k
+        descs.append(d)
+        masks.append(mask)
+    m, v = O.orc_kpm_cell(descs[0], masks[0], descs[1], masks[1].shape)
+    assert m == 1
+    off = (int(v["dx"]), int(v["dy"]))
+    res = splice(list(frags))
+    assert len(res) == 1
+    f = res[0]
+    # frames: the first fragment's stay, the second's move by the vote's offset; then normalize
+    allpos = np.array([p for _, p in f.frames])
+    exp = np.concatenate([poss[0], poss[1] + off])
+    # canvas growth happens in whole frame steps (fgm.hpp:190-233): the merged zero is a step multiple away
+    shift = allpos[0] - exp[0]
+    assert shift[0] % w == 0 and shift[1] % h == 0
+    assert np.array_equal(allpos, exp + shift)
+    ch, cw = f.canvas.shape[0], f.canvas.shape[1]
+    assert cw % w == 0 and ch % h == 0
+    ref = np.zeros((ch, cw, 16), np.uint16)
+    allframes = np.concatenate(parts)
+    for img, p in zip(allframes, allpos):
+        O.orc_fgm_blit(ref, (0, 0), img, p)
+    assert np.array_equal(f.canvas.cpu().numpy().view(np.uint16), ref)
+    # minimal: no empty frame-sized column or row at either side
+    occ = ref.any(axis=2)
+    assert occ[:, :w].any() and occ[:, -w:].any() and occ[:h].any() and occ[-h:].any()

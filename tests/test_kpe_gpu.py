@@ -103,3 +103,36 @@ def test_kpe_widths_not_multiple_of_four(gpu):
         noise = rng.integers(0, 16, size=(H, W), dtype=np.uint8)
         frames = np.ascontiguousarray(np.stack([img, np.roll(img, 2, axis=1), noise, np.roll(img, 3, axis=0)]))
         check_against_oracle(frames, grid=grid, overlap=ov, kmax=16384)
+
+
+def test_kpe_large_frame_sort_path_kmax_16384(gpu):
+    """A frame above 524 288 pixels has no rank bitmap: kpe_table_rest sorts 64-bit keys in LDS,
+    128 KB of dynamic LDS at kmax = 16 384 (the default of kpe::extractor in the drop-in layer)
+    — needs the launch attribute; more than 8 192 keypoints so the sort really is that wide."""
+    rng = np.random.default_rng(23)
+    H, W = 768, 1024
+    img = np.full((H, W), 6, np.uint8)
+    m = rng.random((H, W)) < 0.15
+    img[m] = rng.integers(0, 16, int(m.sum()))
+    k = O.orc_kpe(img, 1, 1, 0)[2]
+    assert 8192 < k <= 16384, k
+    check_against_oracle(img[None], grid=(1, 1), overlap=0, kmax=16384)
+    check_against_oracle(img[None], grid=(4, 2), overlap=16, kmax=16384)
+
+
+def test_kpe_fused_kernel_matches_oracle(gpu, monkeypatch):
+    """The single-kernel variant (kpe_fused.hip, opt-in through RMX_KPE_FUSED: measured slower
+    than kpe_main + kpe_finish) gives the same tables: widths that are and are
+    not multiples of 16, partial last strips, several frames per workgroup, dense frames that
+    need more than one pass over the candidate queue."""
+    monkeypatch.setenv("RMX_KPE_FUSED", "1")
+    frames, _ = scroller_v1(9, dens=40)
+    check_against_oracle(frames)
+    rng = np.random.default_rng(29)
+    for (H, W, grid, ov) in [(41, 132, (1, 1), 0), (60, 324, (4, 2), 16), (100, 64, (1, 1), 0), (250, 1284, (4, 2), 16)]:
+        base = rng.integers(0, 16, size=(H // 5 + 1, W // 5 + 1), dtype=np.uint8)
+        img = np.kron(base, np.ones((5, 5), np.uint8))[:H, :W]
+        small = H * W < 20000
+        third = rng.integers(0, 16, size=(H, W), dtype=np.uint8) if small else np.roll(img, 7, axis=1)
+        frames = np.ascontiguousarray(np.stack([img, np.roll(img, 2, axis=1), third, np.roll(img, 3, axis=0), img]))
+        check_against_oracle(frames, grid=grid, overlap=ov, kmax=16384)
