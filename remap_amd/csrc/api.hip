@@ -17,6 +17,7 @@
 #include "table.hip"
 #include "kpm.hip"
 #include "kpm_cell.hip"
+#include "fgs_big.hip"
 #include "fgm.hip"
 #include "nic.hip"
 #include "fdf.hip"

@@ -12,7 +12,8 @@
 //     keypoints inside the overlap whose translated position is covered by the previous mask;
 //   accept unless matched_cells < active * 0.66f (kpm.hpp:388) — the path's only fp32 op,
 //     evaluated with the same two IEEE single operations.
-// One wave per pair; all tables in LDS.
+// One wave per pair; all tables in LDS.  A pair that outgrows them (more than KC_DMAX distinct
+// offsets, a full (offset, cell) set) is marked valid = 2 and matched by fgs_big.hip.
 #include "common.h"
 
 namespace rmx {
@@ -182,8 +183,8 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
     D += (uint32_t)__shfl_xor((int)D, o);
     F += (uint32_t)__shfl_xor((int)F, o);
   }
-  if (D > KC_DMAX || F != 0) {
-    if (lane == 0) atomicOr(&p.status[1], 16u);
+  if (D > KC_DMAX || F != 0) {  // does not fit these tables: the host sends the pair to fgs_big.hip
+    if (lane == 0) out->valid = 2u;
     return;
   }
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(64) void kpm_cell_match(KpmCellParams p) {
     fail2 += (uint32_t)__shfl_xor((int)fail2, o);
   }
   if (fail2) {
-    if (lane == 0) atomicOr(&p.status[1], 32u);
+    if (lane == 0) out->valid = 2u;
     return;
   }
   // ---- e. kpm.hpp:388 ----

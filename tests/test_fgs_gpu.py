@@ -16,8 +16,13 @@ pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
 
 
-def test_cellular_match_golden_pairs(gpu):
+@pytest.mark.parametrize("big", [False, True])
+def test_cellular_match_golden_pairs(gpu, big, monkeypatch):
+    """big: every pair through the global-memory instance (fgs_big.hip) instead of the LDS one"""
     import torch
+
+    if big:
+        monkeypatch.setenv("RMX_FGS_BIG", "1")
 
     g = np.load(os.path.join(G, "kpm_cell_cases.npz"))
     nf = int(g["nfrag"])
@@ -48,8 +53,12 @@ def test_cellular_match_golden_pairs(gpu):
     ctx.close()
 
 
-def test_collect_then_splice_matches_reference(gpu):
+@pytest.mark.parametrize("big", [False, True])
+def test_collect_then_splice_matches_reference(gpu, big, monkeypatch):
     import torch
+
+    if big:
+        monkeypatch.setenv("RMX_FGS_BIG", "1")
 
     g = np.load(os.path.join(G, "fgs_splice.npz"))
     n, w, h, rooms, dens, seed = g["gen"].tolist()
