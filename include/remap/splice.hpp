@@ -26,11 +26,13 @@ namespace details {
 
 // rows of a snippet's descriptor table: extract_single starts with snippet_kmax and, when a
 // canvas has more keypoints (rmx_kpe_status reports how many), extracts again with the next
-// power of two, up to snippet_kmax_limit = what rmx_kpm_cell_pairs takes per fragment.  The
-// reference has no limit (kpr.hpp:121-124); beyond 4096 keypoints per fragment splice throws
-// remap::device_error(RMX_ERR_KMAX) — INTEGRATION.md §4.
+// power of two (the reference has no limit, kpr.hpp:121-124), up to snippet_kmax_limit = the
+// largest table a context takes; beyond it splice throws remap::device_error(RMX_ERR_KMAX).
+// rmx_kpm_cell_pairs matches pairs of any size (its context only sets the size of the tables
+// that are matched in LDS) — INTEGRATION.md §4.
 inline constexpr std::uint32_t snippet_kmax = 2048;
-inline constexpr std::uint32_t snippet_kmax_limit = 4096;
+inline constexpr std::uint32_t snippet_kmax_limit = 1u << 22;
+inline constexpr std::uint32_t cell_ctx_kmax = 4096;
 inline constexpr kpm::cell_size_t cell_size{15, 15};  // fgs.hpp:121
 
 struct snippet;
@@ -82,8 +84,8 @@ inline snippet extract_single(fgm::fragment&& fragment) {
     }
     if (st == RMX_ERR_KMAX)
       throw remap::device_error(st, "fgs::splice: a fragment of " + std::to_string(w) + "x" + std::to_string(h) + " has " +
-                                        std::to_string(need) + " keypoints; rmx_kpm_cell_pairs takes at most " +
-                                        std::to_string(snippet_kmax_limit) + " per fragment");
+                                        std::to_string(need) + " keypoints; a descriptor table holds at most " +
+                                        std::to_string(snippet_kmax_limit));
     remap::check(st, c, "rmx_kpe_status");
     break;
   }
@@ -113,7 +115,7 @@ void match_partial(It head, It first, It last) {
     pairs.push_back(0);
     pairs.push_back(std::uint32_t(i + 1));
   }
-  rmx_ctx* c = remap::context_cache::get(16, 8, 1, 1, 0, snippet_kmax_limit);
+  rmx_ctx* c = remap::context_cache::get(16, 8, 1, 1, 0, cell_ctx_kmax);
   std::vector<rmx_vote> votes(others.size());
   remap::check(rmx_kpm_cell_pairs(c, tables.data(), counts.data(), masks.data(), dims.data(),
                                   std::uint32_t(tables.size()), pairs.data(), std::uint32_t(others.size()),

@@ -34,6 +34,7 @@ struct rmx_ctx {
   uint32_t* kraw = nullptr;
   uint32_t* tflag = nullptr;  // per frame: left to kpe_table_rest
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
+  uint32_t* tab_ws = nullptr;  // kpe_table_big (kmax > 16 384): 2 * ceil(W*H/32) dwords per frame
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
@@ -72,6 +73,9 @@ struct rmx_ctx {
 };
 
 namespace {
+
+constexpr uint32_t KPE_KMAX_LDS = 16384;      // tables the LDS instances of kpe_table sort
+constexpr uint32_t KPE_KMAX_MAX = 1u << 22;   // rows per table a context may ask for (kpe_table_big above KPE_KMAX_LDS)
 
 #define RMX_HIP(call)                                                                    \
   do {                                                                                   \
@@ -160,6 +164,8 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->cand) (void)hipFree(ctx->cand);
+  if (ctx->tab_ws) (void)hipFree(ctx->tab_ws);
+  ctx->tab_ws = nullptr;
   ctx->raw = nullptr;
   ctx->kraw = nullptr;
   ctx->tflag = nullptr;
@@ -170,6 +176,7 @@ int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->tflag, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->cand, cand_bytes));
+  if (ctx->kmax > KPE_KMAX_LDS) RMX_HIP(hipMalloc(&ctx->tab_ws, (size_t)n * 2 * (((size_t)ctx->W * ctx->H + 31) / 32) * sizeof(uint32_t)));
   ctx->n_cap = n;
   ctx->ws_bytes = (size_t)n * ctx->kmax * sizeof(RawDesc) + (size_t)n * 4 + cand_bytes + kpm_workspace_bytes(ctx->kpm);
   return RMX_OK;
@@ -236,7 +243,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   // kpe.hpp:84-90 needs every region to start inside the frame.  x,y are uint16 in rmx_desc.
   if (width < 16 || height < 8 || width > 65532 || height > 65535) return RMX_ERR_ARG;
   if (grid_w < 1 || grid_h < 1 || grid_w > 4 || grid_h > 4 || grid_w * grid_h > 8) return RMX_ERR_ARG;
-  if (kmax < 1 || kmax > 16384) return RMX_ERR_ARG;
+  if (kmax < 1 || kmax > KPE_KMAX_MAX) return RMX_ERR_ARG;
   {
     uint32_t rw = width / grid_w, rh = height / grid_h;
     if (rw <= overlap / 2 || rh <= overlap / 2) return RMX_ERR_ARG;
@@ -282,6 +289,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->kraw) (void)hipFree(ctx->kraw);
   if (ctx->cand) (void)hipFree(ctx->cand);
+  if (ctx->tab_ws) (void)hipFree(ctx->tab_ws);
   if (ctx->status) (void)hipFree(ctx->status);
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->fdf_ws) (void)hipFree(ctx->fdf_ws);
@@ -570,7 +578,10 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     tp.rank_words = (uint32_t)words;
     lds = std::max<size_t>(128 * sizeof(uint64_t), words * 4);  // the sort then only sees frames with <= 128 keypoints
   }
-  {
+  if (ctx->kmax > KPE_KMAX_LDS) {
+    Timer t(ctx, &ctx->ms_table);
+    hipLaunchKernelGGL(kpe_table_big, dim3(n), dim3(1024), 0, ctx->stream, tp, ctx->tab_ws, (uint32_t)words);
+  } else {
     Timer t(ctx, &ctx->ms_table);
     tp.wave_ok = ctx->W <= 1024 && ctx->H <= 1024 && ctx->kmax <= 2048;
     tp.left = ctx->tflag;

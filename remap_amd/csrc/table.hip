@@ -208,4 +208,53 @@ __global__ __launch_bounds__(256) void kpe_table_rest(TableParams p) {
   }
 }
 
+// Tables of any size (contexts with kmax above 16 384: the blended canvases of large fragments,
+// fgs.hpp:80-89): the rank bitmap of kpe_table_block — a keypoint's row is the number of
+// keypoints before it in scan order — kept in global memory, one workgroup of 1 024 threads per
+// frame.  scratch: 2 * ceil(W * H / 32) dwords per frame (bits, running counts).
+__global__ __launch_bounds__(1024) void kpe_table_big(TableParams p, uint32_t* scratch, uint32_t words) {
+  __shared__ uint32_t s_base[1024];
+  __shared__ uint32_t s_wave[16];
+  const uint32_t f = blockIdx.x, tid = threadIdx.x;
+  uint32_t k = p.kcount[f];
+  if (k > p.kmax) k = p.kmax;  // overflow already flagged
+  const RawDesc* raw = p.raw + (size_t)f * p.kmax;
+  rmx_desc* out = p.desc + (size_t)f * p.kmax;
+  uint32_t* bm = scratch + (size_t)f * 2 * words;
+  uint32_t* pre = bm + words;
+  for (uint32_t w = tid; w < words; w += 1024) bm[w] = 0;
+  __syncthreads();
+  for (uint32_t i = tid; i < k; i += 1024) {
+    const uint32_t xy = raw[i].xy, b = (xy & 0xffffu) * p.H + (xy >> 16);
+    atomicOr(&bm[b >> 5], 1u << (b & 31u));
+  }
+  __syncthreads();
+  const uint32_t per = (words + 1023) / 1024;
+  const uint32_t w0 = min(words, tid * per), w1 = min(words, w0 + per);
+  uint32_t cnt = 0;
+  for (uint32_t w = w0; w < w1; ++w) {
+    pre[w] = cnt;  // set bits before word w inside the thread's chunk
+    cnt += __popc(bm[w]);
+  }
+  const uint32_t lane = tid & 63u, wave = tid >> 6;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  if (lane == 63) s_wave[wave] = incl;
+  __syncthreads();
+  uint32_t base = 0;
+  for (uint32_t w = 0; w < wave; ++w) base += s_wave[w];
+  s_base[tid] = base + incl - cnt;
+  __syncthreads();
+  for (uint32_t i = tid; i < k; i += 1024) {
+    const RawDesc& r = raw[i];
+    const uint32_t b = (r.xy & 0xffffu) * p.H + (r.xy >> 16), w = b >> 5;
+    write_row(p, out, s_base[w / per] + pre[w] + __popc(bm[w] & ((1u << (b & 31u)) - 1u)), r);
+  }
+  if (tid == 0) p.kout[f] = k;
+}
+
 }  // namespace rmx

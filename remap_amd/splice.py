@@ -14,11 +14,12 @@ from . import lib as L
 
 CELL = (15, 15)  # fgs.hpp:121
 # Rows of a snippet's descriptor table: extraction starts with SNIPPET_KMAX and is repeated with
-# the next power of two when a canvas has more keypoints, up to SNIPPET_KMAX_LIMIT = what
-# rmx_kpm_cell_pairs takes per fragment (the reference has no limit; beyond it splice raises
-# RemapError(RMX_ERR_KMAX)).
+# the next power of two when a canvas has more keypoints (the reference has no limit), up to
+# SNIPPET_KMAX_LIMIT = the largest table a context takes.  rmx_kpm_cell_pairs matches pairs of
+# any size; CELL_CTX_KMAX only sets the size of the tables it matches in LDS.
 SNIPPET_KMAX = 2048
-SNIPPET_KMAX_LIMIT = 4096
+SNIPPET_KMAX_LIMIT = 1 << 22
+CELL_CTX_KMAX = 4096
 
 
 class Fragment:
@@ -116,8 +117,8 @@ def _extract_single(ctx_cache, frag, device):  # fgs.hpp:80-89
             continue
         if rc:
             raise L.RemapError(rc, "rmx_kpe_status",
-                               f"a fragment of {w}x{h} has {maxk} keypoints; rmx_kpm_cell_pairs takes at most "
-                               f"{SNIPPET_KMAX_LIMIT} per fragment")
+                               f"a fragment of {w}x{h} has {maxk} keypoints; a descriptor table holds at most "
+                               f"{SNIPPET_KMAX_LIMIT}")
         return _Snippet(frag, mask, desc[0], int(kc[0].item()))
 
 
@@ -133,7 +134,7 @@ def splice(fragments, device=0, dist=None, group=None):
 
     def ctx_cache(key):
         if key not in ctxs:
-            w, h, kmax = (16, 8, SNIPPET_KMAX_LIMIT) if key == "any" else key
+            w, h, kmax = (16, 8, CELL_CTX_KMAX) if key == "any" else key
             ctxs[key] = L.Context(w, h, grid=(1, 1), overlap=0, kmax=kmax, device=device)
         return ctxs[key]
 

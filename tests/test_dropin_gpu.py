@@ -281,8 +281,8 @@ def test_splice_drop_in_fragments_beyond_2048_keypoints(gpu, tmp_path):
     the oracle's blits at the reported positions, the relative positions the oracle's offsets."""
     exe = build_driver(str(tmp_path))
     w, h = 320, 240
-    frames, _ = scroller_v1(150, dens=30)
-    a, b = frames[:110], frames[40:]  # 2 962 and 2 942 keypoints, 3 281 once merged
+    frames, _ = scroller_v1(300, dens=30)
+    a, b = frames[:170], frames[130:]  # 3 519 and 3 317 keypoints, 4 750 once merged
     stream = np.concatenate([a, np.full((1, h, w), 6, np.uint8), b])
     blob = tmp_path / "long.bin"
     stream.tofile(blob)

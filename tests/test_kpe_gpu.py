@@ -136,3 +136,16 @@ def test_kpe_fused_kernel_matches_oracle(gpu, monkeypatch):
         third = rng.integers(0, 16, size=(H, W), dtype=np.uint8) if small else np.roll(img, 7, axis=1)
         frames = np.ascontiguousarray(np.stack([img, np.roll(img, 2, axis=1), third, np.roll(img, 3, axis=0), img]))
         check_against_oracle(frames, grid=grid, overlap=ov, kmax=16384)
+
+
+def test_kpe_tables_beyond_16384_rows(gpu):
+    """contexts with kmax above 16 384 (blended canvases of large fragments): kpe_table_big ranks
+    the keypoints through a bitmap in global memory — a noise canvas with ~60 000 keypoints"""
+    rng = np.random.default_rng(31)
+    H, W = 300, 420
+    img = rng.integers(0, 16, size=(1, H, W), dtype=np.uint8)
+    k = O.orc_kpe(img[0], 1, 1, 0)[2]
+    assert k > 16384
+    check_against_oracle(img, grid=(1, 1), overlap=0, kmax=1 << 17)
+    two = np.ascontiguousarray(np.stack([img[0], np.roll(img[0], 5, axis=1)]))
+    check_against_oracle(two, grid=(1, 1), overlap=0, kmax=1 << 17)
