@@ -304,7 +304,8 @@ __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x
   }
   const uint32_t p5 = t;
   const bool kp = active && (p3 != p5);
-  if (__builtin_amdgcn_ballot_w64(kp) == 0) return;
+  const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
+  if (km == 0) return;
   const uint32_t weight = (p1 != p5) ? 2u : 1u;
   // code bytes (kpe.hpp:342-379): see oracle/remap_oracle.cpp encode_ref for the derivation
   uint32_t a0 = nib16(w[0]);
@@ -315,8 +316,14 @@ __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x
   uint32_t a3 = nib16((w[3] >> 8) | (e[3] << 24));
   uint32_t a4 = nib16(w[4]);
   uint32_t b12 = weight | (e[4] << 4);
+  // one atomic per wave for the keypoints of its lanes (f is the workgroup's frame): dense
+  // stream 0.81 -> 0.78 ms per 10 000 frames, sparse unchanged
+  uint32_t base = 0;
+  const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(km));
+  if (lane_id() == leader) base = atomicAdd(&p.kcount[f], (uint32_t)__builtin_popcountll(km));
+  base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
   if (kp) {
-    uint32_t slot = atomicAdd(&p.kcount[f], 1u);
+    const uint32_t slot = base + mbcnt(km);
     if (slot < p.kmax) {
       RawDesc* dd = p.raw + (size_t)f * p.kmax + slot;
       uint4 c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);

@@ -165,7 +165,7 @@ class Aligner:
             self._bufs[name] = b
         return b
 
-    def align(self, frames, n_total=None, blit=False, check=True, compress=False):
+    def align(self, frames, n_total=None, blit=False, check=True, compress=False, defer=False):
         """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
 
         Returns a dict with device tensors for the LOCAL block (frames lo..hi of the stream):
@@ -177,7 +177,12 @@ class Aligner:
         blit=True, `canvases` for the fragments that have frames on this rank; if compress=True, `nic_image` and `nic_median`: the
         nic::compress blobs of every local frame and median as (blobs (n, stride), sizes (n,))
         device tensors — what collect stores with each frame (frc.hpp:118) behind main.cpp's
-        codec."""
+        codec.
+
+        defer=True enqueues the step and returns without waiting for it (`nfrag` is None, no status
+        check): a stream of blocks is aligned back to back and the host waits once, in
+        `finish()`, which returns the fragment count of the last step and raises if ANY of the
+        deferred steps overflowed a table or a matcher limit (the status words are sticky)."""
         t = self.torch
         ctx = self.ctx
         n = frames.shape[0]
@@ -195,9 +200,13 @@ class Aligner:
             if self.rank > 0:
                 halo = (tabs[self.rank - 1].contiguous(), cnts[self.rank - 1:self.rank].contiguous())
         dxdy, matched = ctx.kpm_seq(desc, kcount, halo=halo)
-        if self.world == 1:
+        if self.world == 1 and not defer:
             pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)  # synchronises
             nfrag = carry[1] + 1
+        elif self.world == 1:
+            pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=True)
+            ctx.frc_apply_blocks(mine, 0, 1, pos, frag)  # (leaves the fragment count for finish())
+            nfrag = None
         else:
             # every rank scans its block on its own; the blocks' 16-byte summaries (did a fragment
             # start in it, where its last frame sits relative to that start or to the block's
@@ -206,9 +215,12 @@ class Aligner:
             pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
             summ = _all_gather_flat(mine, self.world, self.dist, self.group)
             ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
-            nfrag = ctx.frc_finish()
+            nfrag = None if defer else ctx.frc_finish()
         out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
                    lo=lo, hi=hi, nfrag=nfrag, n_total=n_total)
+        if defer:
+            assert not blit, "canvases need the positions on the host: not with defer=True"
+            check = False
         if check:
             rc, _ = ctx.kpe_status(want_max=False)
             if rc:
@@ -226,6 +238,20 @@ class Aligner:
             self.gather_positions(out)
             out["canvases"] = self.blit(frames, out["pos_all"], out["frag_all"], lo, hi)
         return out
+
+    def finish(self):
+        """Wait for the deferred steps: fragment count of the last one; raises if any of them
+        reported an overflow (rmx_kpe_status / rmx_kpm_status)."""
+        ctx = self.ctx
+        nfrag = ctx.frc_finish()
+        rc, _ = ctx.kpe_status(want_max=False)
+        if rc:
+            _, maxk = ctx.kpe_status()
+            raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
+        rc, fl = ctx.kpm_status()
+        if rc:
+            raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
+        return nfrag
 
     def gather_positions(self, out):
         """pos_all / frag_all: positions and fragment ids of the WHOLE stream on every rank

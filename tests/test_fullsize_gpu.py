@@ -49,3 +49,38 @@ def test_ten_thousand_frames(gpu, dens):
         assert k == tabs_k[i] and np.array_equal(med[i].cpu().numpy(), omed)
         assert desc[i, :k].cpu().numpy().tobytes() == odesc.tobytes()
     ctx.close()
+
+
+def test_deferred_steps_equal_synchronous_ones(gpu):
+    """Aligner.align(defer=True): steps enqueued back to back, one host wait in finish() — same
+    offsets, positions, fragment ids and fragment count as the synchronous step; an overflow in
+    any deferred step surfaces in finish()."""
+    import torch
+
+    from remap_amd.pipeline import Aligner
+
+    frames, truth = scroller_v1(600, dens=100)
+    frames = frames.copy()
+    frames[200] = 6  # fragment breaks
+    frames[433] = 6
+    d = torch.from_numpy(frames).cuda()
+    al = Aligner(320, 240, kmax=2048)
+    ref = al.align(d)
+    want = {k: ref[k].clone() for k in ("dxdy", "matched", "pos", "frag", "kcount")}
+    for _ in range(3):
+        out = al.align(d, defer=True)
+        assert out["nfrag"] is None
+    assert al.finish() == ref["nfrag"]
+    for k, v in want.items():
+        assert torch.equal(out[k], v), k
+    al.close()
+    # sticky status: a table overflow in the FIRST of three deferred steps is reported at the end
+    rng = np.random.default_rng(1)
+    noise = torch.from_numpy(rng.integers(0, 16, size=(4, 240, 320), dtype=np.uint8)).cuda()
+    al = Aligner(320, 240, kmax=256)
+    al.align(noise, defer=True)
+    al.align(d[:4].contiguous(), defer=True)
+    al.align(d[:4].contiguous(), defer=True)
+    with pytest.raises(L.RemapError):
+        al.finish()
+    al.close()
