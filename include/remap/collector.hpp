@@ -272,7 +272,23 @@ public:
         continue;
       }
       remap::check(kst, ctx_, "rmx_kpe_status");
-      remap::check(rmx_kpm_status(ctx_, nullptr), ctx_, "rmx_kpm_status");
+      std::uint32_t kflags = 0;
+      int mst = rmx_kpm_status(ctx_, &kflags);
+      if (mst == RMX_ERR_CAPACITY && kflags == 128u) {
+        // tickets the LDS matcher left to its global-memory instance (thousands of keypoints in
+        // one region): computed there, offsets rewritten, positions derived again
+        auto const* hd = first ? nullptr : halo_.get<rmx_desc>();
+        auto const* hk = first ? nullptr : reinterpret_cast<std::uint32_t const*>(halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc));
+        remap::check(rmx_kpm_resolve(ctx_, desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>(), n, hd, hk, dxdy_.get<std::int32_t>(),
+                                     matched_.get<std::uint8_t>(), nullptr),
+                     ctx_, "rmx_kpm_resolve");
+        carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
+        remap::check(rmx_frc_scan(ctx_, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0, carry_pos,
+                                  &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
+                     ctx_, "rmx_frc_scan");
+        mst = RMX_OK;
+      }
+      remap::check(mst, ctx_, "rmx_kpm_status");
       break;
       }
       // the last table is the next block's halo

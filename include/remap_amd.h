@@ -135,8 +135,20 @@ int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint
 
 /* Synchronises; returns RMX_ERR_CAPACITY if a matcher workspace limit (groups per frame,
  * shared codes or distinct offsets per region pair) was exceeded since the last call —
- * the affected results are then invalid.  *flags (may be NULL) receives the limit bits. */
+ * the affected results are then invalid.  *flags (may be NULL) receives the limit bits:
+ * 128 alone = only tickets that rmx_kpm_resolve can still compute are missing. */
 int rmx_kpm_status(rmx_ctx* ctx, uint32_t* flags);
+
+/* The tickets rmx_kpm_seq left to the global-memory instance of the matcher: a region of a frame
+ * with more than 4 096 entries, or a (pair, region) with more shared codes / distinct offsets
+ * than the LDS instances hold (rmx_kpm_status then returns RMX_ERR_CAPACITY with flag bit 128
+ * and no other bit).  Computes them (same arguments as the rmx_kpm_seq call they belong to),
+ * re-runs declare (kpm.hpp:199-211) and rewrites dxdy / matched; *resolved (may be NULL) =
+ * number of tickets.  Positions derived from the old dxdy / matched (rmx_frc_scan) must be
+ * derived again.  Synchronises; a no-op returning RMX_OK when nothing was left. */
+int rmx_kpm_resolve(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint32_t n,
+                    const rmx_desc* halo_desc, const uint32_t* halo_kcount, int32_t* dxdy,
+                    uint8_t* matched, uint32_t* resolved);
 
 /* Diagnostics: the per-region tickets (kpm::details::cast_vote, kpm.hpp:213-223; top-3
  * offsets by count, ties in unordered_map iteration order) of the last rmx_kpm_seq call.

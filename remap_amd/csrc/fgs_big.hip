@@ -19,6 +19,9 @@
 //   fgb_vote    votes and first touch per offset, distinct cells per offset (kpm.hpp:231-264),
 //               find_best with libstdc++'s tie order (kpm.hpp:281-298), active cells
 //               (kpm.hpp:302-367) and the 0.66f test (kpm.hpp:388).
+// The same tables serve the grid matcher (kpm.hpp:395-415) where a frame's region outgrows the
+// LDS instances of kpm.hip: fgb_rows cuts a region's rows out of a frame's table, fgb_ticket
+// writes the region's ticket (rmx_kpm_resolve).
 //
 // Bit-exactness on ties needs the iteration order of unordered_maps with up to millions of
 // nodes: umap_order_big is umap_order_par (kpm.hpp) on global scratch, with libstdc++'s bucket
@@ -156,7 +159,8 @@ __device__ inline void umap_order_big(const uint64_t* h, uint32_t n, uint32_t* c
 // ---- per fragment -------------------------------------------------------------------------------------
 
 struct FgbFrag {
-  const rmx_desc* desc;  // K rows in scan order
+  const rmx_desc* desc;  // table; the fragment's K rows in scan order are desc[rows[i]] (rows == null: desc[i])
+  const uint32_t* rows;
   const uint8_t* mask;   // blend mask, w x h
   uint32_t K, w, h;
   uint32_t HTS;          // slots of the code table (power of two >= 2 K)
@@ -208,7 +212,8 @@ inline void fgb_carve_frag(FgbCarver& c, FgbFrag& f) {
 
 __global__ __launch_bounds__(FGB_NT) void fgb_build(const FgbFrag* frags) {
   const FgbFrag F = frags[blockIdx.x];
-  const uint32_t tid = threadIdx.x, K = F.K, mask = F.HTS - 1;
+  const uint32_t tid = threadIdx.x, K = F.K, hmask = F.HTS - 1;
+  auto row = [&](uint32_t i) { return F.rows ? F.rows[i] : i; };
   for (uint32_t s = tid; s < F.HTS; s += FGB_NT) {
     F.ht[s] = 0;
     F.cnt[s] = 0;
@@ -220,15 +225,15 @@ __global__ __launch_bounds__(FGB_NT) void fgb_build(const FgbFrag* frags) {
   // rows -> slots (one slot per distinct code)
   for (uint32_t i = tid; i < K; i += FGB_NT) {
     uint32_t c[4];
-    load_code(F.desc + i, c);
-    uint32_t s = fnv_code_lo(c) & mask;
+    load_code(F.desc + row(i), c);
+    uint32_t s = fnv_code_lo(c) & hmask;
     for (;;) {
       const uint32_t v = atomicCAS(&F.ht[s], 0u, i + 1);
       if (v == 0u) break;
       uint32_t c2[4];
-      load_code(F.desc + (v - 1), c2);
+      load_code(F.desc + row(v - 1), c2);
       if (same_code(c, c2)) break;
-      s = (s + 1) & mask;
+      s = (s + 1) & hmask;
     }
     F.row_slot[i] = s;
     atomicAdd(&F.cnt[s], 1u);
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(FGB_NT) void fgb_build(const FgbFrag* frags) {
   fgb_sort(F.skeys, g2);
   for (uint32_t g = tid; g < G; g += FGB_NT) {
     const uint32_t s = (uint32_t)F.skeys[g];
-    F.gfirst[g] = (uint32_t)(F.skeys[g] >> 32);
+    F.gfirst[g] = row((uint32_t)(F.skeys[g] >> 32));  // the table row that holds the group's code
     F.ht[s] = g + 1;
     F.unxt[g] = F.cnt[s];  // group sizes, scanned below
   }
@@ -255,7 +260,7 @@ __global__ __launch_bounds__(FGB_NT) void fgb_build(const FgbFrag* frags) {
   const uint32_t k2 = fgb_pow2(K);
   for (uint32_t i = tid; i < k2; i += FGB_NT) F.skeys[i] = i < K ? (uint64_t)(F.ht[F.row_slot[i]] - 1) << 32 | i : ~0ull;
   fgb_sort(F.skeys, k2);
-  for (uint32_t q = tid; q < K; q += FGB_NT) F.pts[q] = load_xy(F.desc + (uint32_t)F.skeys[q]);
+  for (uint32_t q = tid; q < K; q += FGB_NT) F.pts[q] = load_xy(F.desc + row((uint32_t)F.skeys[q]));
   // iteration order of the code map
   for (uint32_t g = tid; g < G; g += FGB_NT) {
     uint32_t c[4];
@@ -267,11 +272,63 @@ __global__ __launch_bounds__(FGB_NT) void fgb_build(const FgbFrag* frags) {
   if (tid == 0) F.hdr[0] = G;
 }
 
+// The rows of ONE grid region of a frame's table (kpr::grid region r, kpe.hpp:157-192), in
+// scan order, for the grid matcher's global-memory instance: rows[0..K) and {K, weight-2 rows,
+// weight-1 rows} (kpr.hpp:121-124 weight counters).  One workgroup per (table, region).
+struct FgbRegion {
+  const rmx_desc* desc;
+  uint32_t k, region;
+  uint32_t* rows;   // k entries
+  uint32_t* info;   // [0] K, [1] weight-2 rows, [2] weight-1 rows
+};
+__global__ __launch_bounds__(FGB_NT) void fgb_rows(const FgbRegion* regs) {
+  __shared__ uint32_t s_wave[FGB_NT / 64];
+  __shared__ uint32_t s_w[2];
+  const FgbRegion R = regs[blockIdx.x];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wv = tid >> 6;
+  if (tid < 2) s_w[tid] = 0;
+  const uint32_t per = (R.k + FGB_NT - 1) / FGB_NT;
+  const uint32_t lo = min(R.k, tid * per), hi = min(R.k, lo + per);
+  uint32_t cnt = 0, w2 = 0, w1 = 0;
+  for (uint32_t i = lo; i < hi; ++i)
+    if ((R.desc[i].region_mask >> R.region) & 1u) {
+      ++cnt;
+      const uint32_t wgt = R.desc[i].code[12] & 0xfu;
+      w2 += wgt == 2;
+      w1 += wgt == 1;
+    }
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  if (lane == 63) s_wave[wv] = incl;
+  __syncthreads();
+  uint32_t base = 0, total = 0;
+  for (uint32_t k = 0; k < FGB_NT / 64; ++k) {
+    if (k < wv) base += s_wave[k];
+    total += s_wave[k];
+  }
+  uint32_t at = base + incl - cnt;
+  for (uint32_t i = lo; i < hi; ++i)
+    if ((R.desc[i].region_mask >> R.region) & 1u) R.rows[at++] = i;
+  if (w2) atomicAdd(&s_w[0], w2);
+  if (w1) atomicAdd(&s_w[1], w1);
+  __syncthreads();
+  if (tid == 0) {
+    R.info[0] = total;
+    R.info[1] = s_w[0];
+    R.info[2] = s_w[1];
+  }
+}
+
 // ---- per pair -----------------------------------------------------------------------------------------
 
 struct FgbPair {
   uint32_t fp, fc;   // previous, current fragment (indices into the FgbFrag array)
-  uint32_t out;      // index of the pair in the caller's vote array
+  uint32_t out;      // index of the pair in the caller's vote array (grid matcher: ticket index)
+  uint32_t w2_only;  // grid matcher, kpm.hpp:112-117: only codes of weight 2 vote (both regions rich in them)
   uint32_t HS, PS;   // slots of the offset table / of the (offset, cell) set (powers of two)
   uint32_t Dcap;     // distinct offsets the tie scratch holds
   // per current code, in iteration order (Kc + 1 entries): previous group and pairs before it
@@ -346,6 +403,7 @@ __global__ __launch_bounds__(FGB_NT) void fgb_count(const FgbFrag* frags, const 
       }
       s = (s + 1) & pmask;
     }
+    if (Q.w2_only && (c[3] & 0xfu) != 2u) np = 0;
     const uint64_t pr = (uint64_t)np * (C.gstart[gc + 1] - C.gstart[gc]);
     if (pr > 0x7fffffffull) Q.total[1] = 1;
     Q.gpk[k] = gp;
@@ -553,6 +611,99 @@ __global__ __launch_bounds__(FGB_NT) void fgb_vote(const FgbFrag* frags, const F
   if (tid == 0) {
     const float lhs = (float)matched_cells, rhs = (float)act * 0.66f;
     if (!(lhs < rhs)) *out = rmx_vote{bdx, bdy, cmax, 1u};
+  }
+}
+
+// Grid matcher (kpm.hpp:395-415), one (pair, region): cast_vote = top_offsets(count_offsets, 3)
+// (kpm.hpp:105-159) — the three offsets with most votes, equal counts in the totalizator's
+// iteration order — written as the ticket kpm_declare reads: {key, count} x 3, key 0 ends it.
+__global__ __launch_bounds__(FGB_NT) void fgb_ticket(const FgbFrag* frags, const FgbPair* pairs, uint32_t* tickets, uint32_t* status) {
+  __shared__ uint64_t s_red64[FGB_NT / 64];
+  __shared__ uint32_t s_red32[FGB_NT / 64];
+  const FgbPair Q = pairs[blockIdx.x];
+  const FgbFrag P = frags[Q.fp], C = frags[Q.fc];
+  const uint32_t tid = threadIdx.x;
+  uint32_t* ticket = tickets + (size_t)Q.out * 6;
+  if (tid < 6) ticket[tid] = 0;
+  const uint32_t total = Q.total[0];
+  if (total == 0) return;
+  const uint32_t Gc = C.hdr[0];
+  for (uint32_t s = tid; s < Q.HS; s += FGB_NT) {
+    Q.hk[s] = 0;
+    Q.hc[s] = 0;
+    Q.hs[s] = 0xffffffffu;
+  }
+  if (tid < 8) Q.ctl[tid] = 0;
+  __syncthreads();
+  uint32_t my_new = 0, my_fail = 0;
+  const uint32_t hmask = Q.HS - 1;
+  for (uint32_t t = tid; t < total; t += FGB_NT) {
+    uint32_t lo = 0, hi = Gc;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (Q.base[mid] <= t)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    const uint32_t gc = C.giter[lo], gp = Q.gpk[lo], rel = t - Q.base[lo];
+    const uint32_t cs = C.gstart[gc], nc = C.gstart[gc + 1] - cs;
+    const uint32_t ip = rel / nc, ic = rel - ip * nc;
+    const uint32_t pp = P.pts[P.gstart[gp] + ip], cp = C.pts[cs + ic];
+    const uint32_t key = off_key((int32_t)(pp & 0xffffu) - (int32_t)(cp & 0xffffu), (int32_t)(pp >> 16) - (int32_t)(cp >> 16));
+    uint32_t s = (key * 2654435761u) & hmask;
+    bool placed = false;
+    for (uint32_t probes = 0; probes <= hmask; ++probes) {
+      const uint32_t v = atomicCAS(&Q.hk[s], 0u, key);
+      if (v == 0u) ++my_new;
+      if (v == 0u || v == key) {
+        atomicAdd(&Q.hc[s], 1u);
+        atomicMin(&Q.hs[s], t);
+        placed = true;
+        break;
+      }
+      s = (s + 1) & hmask;
+    }
+    if (!placed) ++my_fail;
+  }
+  const uint32_t D = fgb_sum_u32(my_new, s_red32);
+  const uint32_t Fl = fgb_sum_u32(my_fail, s_red32);
+  if (Fl != 0 || D > Q.Dcap) {
+    if (tid == 0) atomicOr(&status[1], 16u);
+    return;
+  }
+  // the totalizator's nodes in insertion (= first touch) order, then in iteration order
+  for (uint32_t s = tid; s < Q.HS; s += FGB_NT)
+    if (Q.hk[s] != 0) Q.skeys[atomicAdd(&Q.ctl[0], 1u)] = (uint64_t)Q.hs[s] << 32 | s;
+  __syncthreads();
+  const uint32_t d2 = fgb_pow2(D);
+  for (uint32_t i = D + tid; i < d2; i += FGB_NT) Q.skeys[i] = ~0ull;
+  fgb_sort(Q.skeys, d2);
+  uint32_t* slot_of = Q.pos_of;
+  for (uint32_t i = tid; i < D; i += FGB_NT) {
+    const uint32_t sl = (uint32_t)Q.skeys[i], key = Q.hk[sl];
+    Q.hh[i] = fnv_offset((int32_t)(key >> 16) - 32768, (int32_t)(key & 0xffffu) - 32768);
+    slot_of[i] = sl;
+  }
+  __syncthreads();
+  uint32_t* order = Q.ucur;
+  umap_order_big(Q.hh, D, Q.ucur, Q.unxt, Q.skeys, Q.bmin, order);
+  // top_offsets(total, 3): most votes first, equal counts in iteration order (strict >, kpm.hpp:138)
+  uint64_t taken[3] = {0, 0, 0};
+  for (int rk = 0; rk < 3 && (uint32_t)rk < D; ++rk) {
+    uint64_t m = 0;
+    for (uint32_t k = tid; k < D; k += FGB_NT) {
+      const uint64_t cand = (uint64_t)Q.hc[slot_of[order[k]]] << 32 | (uint64_t)(0xffffffffu - k);
+      bool used = false;
+      for (int j = 0; j < rk; ++j) used |= cand == taken[j];
+      if (!used && cand > m) m = cand;
+    }
+    taken[rk] = fgb_max_u64(m, s_red64);
+    if (tid == 0) {
+      const uint32_t sl = slot_of[order[0xffffffffu - (uint32_t)taken[rk]]];
+      ticket[2 * rk] = Q.hk[sl];
+      ticket[2 * rk + 1] = Q.hc[sl];
+    }
   }
 }
 

@@ -268,6 +268,7 @@ struct KpmWorkspace {
   uint32_t* tickets = nullptr;  // n_cap pairs x 8 regions x 3 x 2 (key, count)
   uint32_t* needs_large = nullptr;  // n_cap + 1 flags written by kpm_build_small
   uint32_t* work = nullptr;         // 1 + n_cap * 8 work items for kpm_match<LARGE>
+  uint32_t* big = nullptr;          // 1 + 24 * (n_cap + 1): items left to rmx_kpm_resolve
   uint32_t n_cap = 0, kmax = 0;
   size_t bytes = 0;
 };
@@ -296,6 +297,7 @@ inline void kpm_workspace_free(KpmWorkspace& w) {
   if (w.tickets) (void)hipFree(w.tickets);
   if (w.needs_large) (void)hipFree(w.needs_large);
   if (w.work) (void)hipFree(w.work);
+  if (w.big) (void)hipFree(w.big);
   w = KpmWorkspace{};
 }
 
@@ -307,6 +309,9 @@ struct KpmBuildParams {
   uint32_t* pool;
   uint32_t* status;
   uint32_t n, kmax, nreg;
+  // work list of the global-memory matcher (rmx_kpm_resolve): (pair * nreg + region) items whose
+  // tickets the LDS instances cannot compute; null = report an overflow as a capacity error
+  uint32_t* big;
 };
 
 __device__ __forceinline__ void load_code(const rmx_desc* d, uint32_t c[4]) {
@@ -415,8 +420,19 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
     for (uint32_t i = i0; i < i1; ++i) cnt += (desc[i].region_mask >> r) & 1u;
     uint32_t e = 0;
     uint32_t w = block_exscan<NT>(cnt, scan_scratch, &e);
-    if (e > KC) {  // more entries in one region than this instance holds: reported, region left empty
-      if (tid == 0) atomicOr(&p.status[1], 64u);
+    if (e > KC) {  // more entries in one region than this instance holds: region left empty here
+      if (tid == 0) {
+        if (p.big) {  // ... and the tickets of the two pairs it takes part in left to rmx_kpm_resolve
+          const uint32_t q0 = is_halo ? 0u : fslot;
+          const bool two = !is_halo && fslot + 1 < p.n;
+          const uint32_t at = atomicAdd(&p.big[0], two ? 2u : 1u);
+          p.big[1 + at] = q0 * p.nreg + r;
+          if (two) p.big[2 + at] = (fslot + 1) * p.nreg + r;
+          atomicOr(&p.status[1], 128u);
+        } else {
+          atomicOr(&p.status[1], 64u);
+        }
+      }
       e = 0;
       w = 0;
       cnt = 0;
@@ -734,6 +750,7 @@ __global__ __launch_bounds__(256) void kpm_build_small(KpmBuildParams p, uint32_
     work[0] = 0;
     work[work_stride] = 0;
     work[2 * work_stride] = 0;
+    if (p.big) p.big[0] = 0;
   }
   kpm_build_small_frame<32, true>(p, needs_large, blockIdx.x);
 }
@@ -970,6 +987,7 @@ struct KpmMatchParams {
   uint32_t n, kmax, nreg;
   uint32_t has_halo;
   uint32_t weight_switch;
+  uint32_t* big;       // items left to rmx_kpm_resolve by the last tier (same layout)
 };
 
 __device__ __forceinline__ uint32_t off_key(int32_t dx, int32_t dy) {
@@ -1209,10 +1227,14 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   }
   if (overflow) {
     if (lane == 0) {
-      if (TIER < 2)
+      if (TIER < 2) {
         p.work_out[1 + atomicAdd(&p.work_out[0], 1u)] = item;
-      else
+      } else if (p.big) {
+        p.big[1 + atomicAdd(&p.big[0], 1u)] = item;
+        atomicOr(&p.status[1], 128u);
+      } else {
         atomicOr(&p.status[1], 2u);
+      }
     }
     continue;
   }
@@ -1284,10 +1306,14 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   for (int o = 32; o > 0; o >>= 1) D += (uint32_t)__shfl_xor((int)D, o);
   if (D > KM_DMAX) {
     if (lane == 0) {
-      if (TIER < 2)
+      if (TIER < 2) {
         p.work_out[1 + atomicAdd(&p.work_out[0], 1u)] = item;
-      else
+      } else if (p.big) {
+        p.big[1 + atomicAdd(&p.big[0], 1u)] = item;
+        atomicOr(&p.status[1], 128u);
+      } else {
         atomicOr(&p.status[1], 4u);
+      }
     }
     continue;
   }

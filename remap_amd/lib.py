@@ -30,7 +30,7 @@ STATUS = {0: "RMX_OK", -1: "RMX_ERR_ARG", -2: "RMX_ERR_DEVICE", -3: "RMX_ERR_KMA
 # every symbol include/remap_amd.h declares
 SYMBOLS = [
     "rmx_ctx_create", "rmx_ctx_destroy", "rmx_sync", "rmx_last_error", "rmx_ctx_workspace_bytes",
-    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_frc_scan_block", "rmx_frc_apply_blocks", "rmx_frc_finish", "rmx_fgm_blit_batch", "rmx_fgm_extent",
+    "rmx_kpe_batch", "rmx_kpe_status", "rmx_kpm_seq", "rmx_kpm_status", "rmx_kpm_resolve", "rmx_kpm_tickets", "rmx_frc_scan", "rmx_frc_scan_block", "rmx_frc_apply_blocks", "rmx_frc_finish", "rmx_fgm_blit_batch", "rmx_fgm_extent",
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
@@ -99,6 +99,7 @@ def load():
     lib.rmx_kpe_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
+    lib.rmx_kpm_resolve.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32)]
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
     lib.rmx_frc_scan_block.argtypes = [vp, vp, vp, u32, C.c_int, vp, vp, vp]
@@ -247,6 +248,16 @@ class Context:
         self._chk(self.lib.rmx_kpm_seq(self.h, desc.data_ptr(), kcount.data_ptr(), n, hd, hk, dxdy.data_ptr(),
                                        matched.data_ptr()), "rmx_kpm_seq")
         return dxdy, matched
+
+    def kpm_resolve(self, desc, kcount, dxdy, matched, halo=None):
+        """Tickets the LDS instances left to the global-memory matcher (kpm_status flag 128):
+        computed, declare re-run, dxdy / matched rewritten in place.  Returns their number."""
+        n = desc.shape[0]
+        hd, hk = (halo[0].data_ptr(), halo[1].data_ptr()) if halo is not None else (None, None)
+        res = C.c_uint32()
+        self._chk(self.lib.rmx_kpm_resolve(self.h, desc.data_ptr(), kcount.data_ptr(), n, hd, hk, dxdy.data_ptr(),
+                                           matched.data_ptr(), C.byref(res)), "rmx_kpm_resolve")
+        return res.value
 
     def kpm_status(self):
         fl = C.c_uint32()

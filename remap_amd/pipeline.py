@@ -227,7 +227,15 @@ class Aligner:
                 _, maxk = ctx.kpe_status()
                 raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
             rc, fl = ctx.kpm_status()
-            if rc:
+            if rc == L.RMX_ERR_CAPACITY and fl == 128 and self.world == 1:
+                # regions / pairs the LDS matcher left to its global-memory instance (a frame with
+                # thousands of keypoints in one region): tickets computed there, offsets rewritten,
+                # positions derived again.  (Sharded streams: the ranks would have to agree on taking
+                # this path before their collectives — not wired, the error below is raised instead.)
+                ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
+                pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
+                out.update(pos=pos, frag=frag, nfrag=carry[1] + 1)
+            elif rc:
                 raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
         if compress:
             out["nic_image"] = ctx.nic_compress(frames.reshape(n, -1), pack=False)

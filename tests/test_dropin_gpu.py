@@ -60,6 +60,24 @@ def test_collector_grows_tables_beyond_kmax(gpu, tmp_path):
     check_collect(exe, frames, tmp_path)
 
 
+def test_collector_resolves_huge_regions(gpu, tmp_path):
+    """Frames with a box of pure noise: ~6 000 keypoints, all in one grid region — more than the
+    4 096 entries the LDS matcher holds per region.  The collector grows its tables and lets
+    rmx_kpm_resolve compute the tickets; callbacks, fragments and canvases equal the oracle's."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(16, dens=100)
+    frames = frames.copy()
+    rng = np.random.default_rng(21)
+    big = np.full((240, 320), 6, np.uint8)
+    big[6:126, 6:86] = rng.integers(0, 16, (120, 80))
+    _, dsc, k = O.orc_kpe(big)
+    assert 2048 < k <= 16384 and int((dsc["region_mask"] & 1).sum()) > 4096
+    frames[6] = big
+    frames[7] = np.roll(big, -2, axis=1)
+    frames[8] = np.roll(big, -4, axis=1)
+    check_collect(exe, frames, tmp_path)
+
+
 def check_collect(exe, frames, tmp_path):
     blob = tmp_path / "frames.bin"
     frames.tofile(blob)

@@ -132,7 +132,7 @@ def test_ctx_create_rejects_bad_arguments_without_a_gpu():
            (320, 240, 0, 2, 16, 64),     # empty grid
            (320, 240, 4, 4, 16, 64),     # more than 8 regions
            (320, 240, 4, 2, 16, 0),      # kmax 0
-           (320, 240, 4, 2, 16, 1 << 20),  # kmax too large
+           (320, 240, 4, 2, 16, (1 << 22) + 1),  # kmax too large
            (64, 24, 4, 2, 16, 64)]       # 4x2 bands do not fit (kpe.hpp:84-90)
     for a in bad:
         assert so.rmx_ctx_create(0, *a, None, C.byref(h)) == -1, a

@@ -202,3 +202,74 @@ def test_frc_block_scan_equals_whole_stream_scan(gpu):
             assert torch.equal(torch.cat([p[0] for p in parts]), pos), (trial, world)
             assert torch.equal(torch.cat([p[1] for p in parts]), frag), (trial, world)
     ctx.close()
+
+
+def _boxnoise(seed, shift=0, box=(6, 6, 86, 126), base=None):
+    """a frame whose box is pure noise: ~6 000 keypoints in grid region 0 (and hundreds in its
+    neighbours), more than the 4 096 entries the LDS instances of the matcher hold per region"""
+    rng = np.random.default_rng(seed)
+    img = np.full((240, 320), 6, np.uint8) if base is None else base.copy()
+    x0, y0, x1, y1 = box
+    img[y0:y1, x0:x1] = rng.integers(0, 16, (y1 - y0, x1 - x0))
+    return np.roll(img, -shift, axis=1)
+
+
+def test_grid_matcher_regions_beyond_the_lds_instances(gpu):
+    """Frames with more than 4 096 entries in a grid region, alone and in matching pairs: the LDS
+    instances leave their tickets to the global-memory matcher (rmx_kpm_status flag 128,
+    rmx_kpm_resolve); tickets, offsets and positions equal the oracle's."""
+    import torch
+
+    frames, _ = scroller_v1(12, dens=100)
+    frames = frames.copy()
+    frames[4] = _boxnoise(7)
+    frames[5] = _boxnoise(7, shift=2)   # a matching pair of huge regions
+    frames[6] = _boxnoise(7, shift=5)
+    frames[9] = _boxnoise(8, base=frames[9])  # a huge region in an ordinary frame
+    for i in (4, 9):
+        _, dsc, k = O.orc_kpe(frames[i])
+        assert k <= 16384 and int((dsc["region_mask"] & 1).sum()) > 4096
+    n, H, W = frames.shape
+    ctx = L.Context(W, H, kmax=16384)
+    d = torch.from_numpy(frames).cuda()
+    med, desc, kc = ctx.kpe(d)
+    assert ctx.kpe_status()[0] == 0
+    dxdy, matched = ctx.kpm_seq(desc, kc)
+    rc, fl = ctx.kpm_status()
+    assert rc == L.RMX_ERR_CAPACITY and fl == 128, (rc, fl)
+    nres = ctx.kpm_resolve(desc, kc, dxdy, matched)
+    assert nres > 0
+    tickets = ctx.kpm_tickets(n)
+    pos, frag, carry = ctx.frc_scan(dxdy, matched)
+    o = O.orc_frc(frames)
+    assert np.array_equal(dxdy.cpu().numpy(), o["dxdy"]) and np.array_equal(matched.cpu().numpy(), o["matched"])
+    assert np.array_equal(pos.cpu().numpy(), o["pos"]) and np.array_equal(frag.cpu().numpy(), o["frag"])
+    tabs = L.desc_to_numpy(desc, kc)
+    for q in (4, 5, 6, 7, 9, 10):
+        m, dd, t = O.orc_kpm_grid(tabs[q - 1], tabs[q])
+        for r in range(8):
+            for j in range(3):
+                a, b = tickets[q, r, j], t[r, j]
+                assert int(a["valid"]) == int(b["valid"]), (q, r, j)
+                if int(b["valid"]):
+                    assert (int(a["dx"]), int(a["dy"]), int(a["count"])) == (int(b["dx"]), int(b["dy"]), int(b["count"])), (q, r, j)
+    # a second call finds nothing left
+    assert ctx.kpm_resolve(desc, kc, dxdy, matched) == 0
+    ctx.close()
+
+
+def test_aligner_resolves_huge_regions_by_itself(gpu):
+    import torch
+
+    from remap_amd.pipeline import Aligner
+
+    frames, _ = scroller_v1(10, dens=100)
+    frames = frames.copy()
+    frames[3] = _boxnoise(17)
+    frames[4] = _boxnoise(17, shift=3)
+    al = Aligner(320, 240, kmax=16384)
+    out = al.align(torch.from_numpy(frames).cuda())
+    o = O.orc_frc(frames)
+    assert np.array_equal(out["dxdy"].cpu().numpy(), o["dxdy"]) and np.array_equal(out["pos"].cpu().numpy(), o["pos"])
+    assert out["nfrag"] == int(o["frag"].max()) + 1
+    al.close()
