@@ -301,6 +301,13 @@ int rmx_last_kernel_ms(rmx_ctx* ctx, const char* kernel, float* ms);
  * batch in cache-sized sub-batches, one kpe_main + kpe_finish launch each). */
 int rmx_kernel_launches(rmx_ctx* ctx, const char* kernel, uint32_t* launches);
 
+/* Test hook: the iteration order of a libstdc++ std::unordered_map after inserting n keys whose
+ * 64-bit hashes are hashes[0..n) (device) in index order — the replay the matchers use to break
+ * ties like the reference (kpm.hpp:134-138,297) — as run by the global-memory instances
+ * (fgs_big.hip: umap_order_big).  order[k] (device) = index of the k-th iterated key.
+ * Synchronises. */
+int rmx_debug_umap_order(rmx_ctx* ctx, const uint64_t* hashes, uint32_t n, uint32_t* order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -156,6 +156,12 @@ __device__ inline void umap_order_big(const uint64_t* h, uint32_t n, uint32_t* c
   __syncthreads();
 }
 
+// test hook (rmx_debug_umap_order): the order replay on its own
+__global__ __launch_bounds__(FGB_NT) void fgb_umap_order(const uint64_t* h, uint32_t n, uint32_t* cur, uint32_t* nxt, uint64_t* keys,
+                                                         uint32_t* bmin, uint32_t* order) {
+  umap_order_big(h, n, cur, nxt, keys, bmin, order);
+}
+
 // ---- per fragment -------------------------------------------------------------------------------------
 
 struct FgbFrag {

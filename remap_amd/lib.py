@@ -34,6 +34,7 @@ SYMBOLS = [
     "rmx_fgm_merge", "rmx_fgm_blend", "rmx_kpm_cell_pairs", "rmx_version", "rmx_luts", "rmx_set_timing",
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
+    "rmx_debug_umap_order",
 ]
 
 
@@ -100,6 +101,7 @@ def load():
     lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_resolve.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32)]
+    lib.rmx_debug_umap_order.argtypes = [vp, vp, u32, vp]
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
     lib.rmx_frc_scan_block.argtypes = [vp, vp, vp, u32, C.c_int, vp, vp, vp]
@@ -258,6 +260,12 @@ class Context:
         self._chk(self.lib.rmx_kpm_resolve(self.h, desc.data_ptr(), kcount.data_ptr(), n, hd, hk, dxdy.data_ptr(),
                                            matched.data_ptr(), C.byref(res)), "rmx_kpm_resolve")
         return res.value
+
+    def debug_umap_order(self, hashes):
+        """iteration order of a libstdc++ unordered_map (test hook): int64 CUDA tensor of hashes -> int32 order"""
+        order = self.torch.empty(hashes.shape[0], dtype=self.torch.int32, device=self.device)
+        self._chk(self.lib.rmx_debug_umap_order(self.h, hashes.data_ptr(), hashes.shape[0], order.data_ptr()), "rmx_debug_umap_order")
+        return order
 
     def kpm_status(self):
         fl = C.c_uint32()

@@ -273,3 +273,25 @@ def test_aligner_resolves_huge_regions_by_itself(gpu):
     assert np.array_equal(out["dxdy"].cpu().numpy(), o["dxdy"]) and np.array_equal(out["pos"].cpu().numpy(), o["pos"])
     assert out["nfrag"] == int(o["frag"].max()) + 1
     al.close()
+
+
+@pytest.mark.parametrize("n,kind", [(1, "random"), (13, "random"), (14, "random"), (5000, "random"), (5088, "few"), (120000, "random"),
+                                    (90000, "few"), (400000, "random"), (30000, "equal")])
+def test_unordered_map_order_replay_at_scale(gpu, n, kind):
+    """umap_order_big (the tie-breaking order of the global-memory matchers) against a real
+    std::unordered_map (oracle, libstdc++): random hashes, hashes that fall into a handful of
+    buckets, all-equal hashes; sizes across the rehash points 13, 29, ... 351 061."""
+    import torch
+
+    rng = np.random.default_rng(n)
+    if kind == "random":
+        h = rng.integers(0, 2**63, size=n, dtype=np.uint64) * 2 + rng.integers(0, 2, size=n, dtype=np.uint64)
+    elif kind == "few":
+        h = rng.integers(0, 7, size=n, dtype=np.uint64) * np.uint64(1000003)
+    else:
+        h = np.full(n, 12345678901234567, np.uint64)
+    want = O.orc_umap_order_std(h)
+    ctx = L.Context(16, 8, grid=(1, 1), overlap=0, kmax=64)
+    got = ctx.debug_umap_order(torch.from_numpy(h.view(np.int64)).cuda()).cpu().numpy().astype(np.uint32)
+    ctx.close()
+    assert np.array_equal(got, want)
