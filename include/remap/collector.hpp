@@ -90,24 +90,35 @@ public:
         ctx_{remap::context_cache::get(std::uint32_t(d.width_), std::uint32_t(d.height_), std::uint32_t(Grid::width),
                                        std::uint32_t(Grid::height), std::uint32_t(Overlap), kmax)} {}
 
-  // kpe.hpp:92-108: keypoint grid of `image`; `median` receives the 3x3 rank image
+  // kpe.hpp:92-108: keypoint grid of `image`; `median` receives the 3x3 rank image.  An image
+  // with more keypoints than the table holds is extracted again with a larger one (the
+  // reference has no limit).
   grid_type extract(matrix_type const& image, matrix_type& median, typename grid_type::allocator_type const& alloc) {
     const std::size_t area = dim_.area();
-    buf_.reserve(ctx_, 2 * area + std::size_t(kmax_) * sizeof(rmx_desc) + 16);
-    auto* d_img = buf_.template get<std::uint8_t>();
-    auto* d_med = d_img + area;
-    auto* d_cnt = reinterpret_cast<std::uint32_t*>(d_med + area);
-    auto* d_tab = reinterpret_cast<rmx_desc*>(d_med + area + 16);
-    remap::check(rmx_upload(ctx_, d_img, image.data(), area), ctx_, "rmx_upload");
-    remap::check(rmx_kpe_batch(ctx_, d_img, 1, d_med, d_tab, d_cnt), ctx_, "rmx_kpe_batch");
-    std::uint32_t maxk = 0;
-    remap::check(rmx_kpe_status(ctx_, &maxk), ctx_, "rmx_kpe_status");
-    std::uint32_t k = 0;
-    remap::check(rmx_download(ctx_, &k, d_cnt, 4), ctx_, "rmx_download");
-    rows_.resize(k);
-    if (k) remap::check(rmx_download(ctx_, rows_.data(), d_tab, k * sizeof(rmx_desc)), ctx_, "rmx_download");
-    remap::check(rmx_download(ctx_, median.data(), d_med, area), ctx_, "rmx_download");
-    return remap::detail::table_to_grid<grid_type>(rows_.data(), k, alloc);
+    for (;;) {
+      buf_.reserve(ctx_, 2 * area + std::size_t(kmax_) * sizeof(rmx_desc) + 16);
+      auto* d_img = buf_.template get<std::uint8_t>();
+      auto* d_med = d_img + area;
+      auto* d_cnt = reinterpret_cast<std::uint32_t*>(d_med + area);
+      auto* d_tab = reinterpret_cast<rmx_desc*>(d_med + area + 16);
+      remap::check(rmx_upload(ctx_, d_img, image.data(), area), ctx_, "rmx_upload");
+      remap::check(rmx_kpe_batch(ctx_, d_img, 1, d_med, d_tab, d_cnt), ctx_, "rmx_kpe_batch");
+      std::uint32_t maxk = 0;
+      const int st = rmx_kpe_status(ctx_, &maxk);
+      if (st == RMX_ERR_KMAX && maxk <= (1u << 22)) {
+        while (kmax_ < maxk) kmax_ <<= 1;
+        ctx_ = remap::context_cache::get(std::uint32_t(dim_.width_), std::uint32_t(dim_.height_), std::uint32_t(Grid::width),
+                                         std::uint32_t(Grid::height), std::uint32_t(Overlap), kmax_);
+        continue;
+      }
+      remap::check(st, ctx_, "rmx_kpe_status");
+      std::uint32_t k = 0;
+      remap::check(rmx_download(ctx_, &k, d_cnt, 4), ctx_, "rmx_download");
+      rows_.resize(k);
+      if (k) remap::check(rmx_download(ctx_, rows_.data(), d_tab, k * sizeof(rmx_desc)), ctx_, "rmx_download");
+      remap::check(rmx_download(ctx_, median.data(), d_med, area), ctx_, "rmx_download");
+      return remap::detail::table_to_grid<grid_type>(rows_.data(), k, alloc);
+    }
   }
 
 private:
@@ -150,10 +161,11 @@ template <match_config Cfg, typename Grid>
 std::optional<cdt::offset_t> match(Cfg const&, Grid const& previous, Grid const& current) {
   static_assert(Grid::region_count == 8 && Cfg::region_votes == 3 && Cfg::weight_switch == 10,
                 "the device matcher implements frc::collector's configuration (grid 4x2, votes 3, switch 10)");
-  constexpr std::uint32_t kmax = 2048;
-  rmx_ctx* c = remap::context_cache::get(4096, 4096, 4, 2, 16, kmax);
   auto tp = remap::detail::grid_to_table(previous), tc = remap::detail::grid_to_table(current);
-  if (tp.size() > kmax || tc.size() > kmax) throw remap::device_error(RMX_ERR_KMAX, "kpm::match: more than 2048 keypoints");
+  std::uint32_t kmax = 2048;  // table stride: the next power of two that holds both, up to the matcher's 16 384
+  while (kmax < std::max(tp.size(), tc.size()) && kmax < 16384) kmax <<= 1;
+  if (tp.size() > kmax || tc.size() > kmax) throw remap::device_error(RMX_ERR_KMAX, "kpm::match: more than 16384 keypoints");
+  rmx_ctx* c = remap::context_cache::get(4096, 4096, 4, 2, 16, kmax);
   remap::device_buffer buf{c, 2 * kmax * sizeof(rmx_desc) + 64};
   auto* d_tab = buf.get<rmx_desc>();
   auto* d_cnt = reinterpret_cast<std::uint32_t*>(buf.get<std::uint8_t>() + 2 * kmax * sizeof(rmx_desc));
@@ -164,7 +176,11 @@ std::optional<cdt::offset_t> match(Cfg const&, Grid const& previous, Grid const&
   if (!tc.empty()) remap::check(rmx_upload(c, d_tab + kmax, tc.data(), tc.size() * sizeof(rmx_desc)), c, "rmx_upload");
   remap::check(rmx_upload(c, d_cnt, cnt, 8), c, "rmx_upload");
   remap::check(rmx_kpm_seq(c, d_tab, d_cnt, 2, nullptr, nullptr, d_dxdy, d_m), c, "rmx_kpm_seq");
-  remap::check(rmx_kpm_status(c, nullptr), c, "rmx_kpm_status");
+  std::uint32_t flags = 0;
+  int st = rmx_kpm_status(c, &flags);
+  if (st == RMX_ERR_CAPACITY && flags == 128u)  // a region beyond the LDS matcher: its global-memory instance
+    st = rmx_kpm_resolve(c, d_tab, d_cnt, 2, nullptr, nullptr, d_dxdy, d_m, nullptr);
+  remap::check(st, c, "rmx_kpm_status");
   std::int32_t dxdy[4];
   std::uint8_t m[2];
   remap::check(rmx_download(c, dxdy, d_dxdy, 16), c, "rmx_download");

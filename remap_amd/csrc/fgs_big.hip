@@ -364,11 +364,13 @@ inline void fgb_carve_count(FgbCarver& c, FgbPair& q, uint32_t Kc) {
   q.base = c.take<uint32_t>((size_t)Kc + 1);
   q.total = c.take<uint32_t>(4);
 }
-inline void fgb_carve_vote(FgbCarver& c, FgbPair& q, uint32_t total) {
+// (kc_cells: the current fragment's keypoints when the (offset, cell) set also has to hold the
+// active cells of fgb_vote — at most one per keypoint; 0 for fgb_ticket)
+inline void fgb_carve_vote(FgbCarver& c, FgbPair& q, uint32_t total, uint32_t kc_cells) {
   const uint32_t d = std::min<uint32_t>(std::max<uint32_t>(total, 1), FGB_MAX_NODES);
   q.Dcap = d;
   q.HS = fgb_pow2(std::max<uint32_t>(2 * d, 64));
-  q.PS = fgb_pow2(std::max<uint32_t>(2 * std::max<uint32_t>(total, 32), 64));
+  q.PS = fgb_pow2(std::max<uint32_t>(2 * std::max<uint32_t>(std::max<uint32_t>(total, kc_cells), 32), 64));
   q.hk = c.take<uint32_t>(q.HS);
   q.hc = c.take<uint32_t>(q.HS);
   q.hs = c.take<uint32_t>(q.HS);

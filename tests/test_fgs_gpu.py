@@ -165,7 +165,8 @@ def _random_table(rng, k, ncodes, w, h):
     return d
 
 
-@pytest.mark.parametrize("case", [(6000, 5000, 300, 1), (9000, 7000, 4000, 2), (5000, 300, 40, 3), (20000, 18000, 15000, 4)])
+@pytest.mark.parametrize("case", [(6000, 5000, 300, 1), (9000, 7000, 4000, 2), (5000, 300, 40, 3), (20000, 18000, 15000, 4),
+                                  (6000, 6000, 200000, 5)])  # (5: a handful of shared codes, a thousand active cells)
 def test_cellular_match_large_tables_match_oracle(gpu, case):
     """Fragments above the LDS instance's 4 096 keypoints (fgs_big.hip) against the oracle: few
     codes (many point pairs per code, thousands of distinct offsets, ties at the top resolved in
