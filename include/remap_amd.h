@@ -180,7 +180,10 @@ int rmx_frc_scan(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint
  *   rmx_frc_apply_blocks folds the summaries of the blocks before `rank` (world x 4 int32,
  *                        device, rank order) and moves the block into place: pos and frag_id
  *                        become what rmx_frc_scan over the whole stream gives (frc.hpp:109-115);
- *   rmx_frc_finish       synchronises once; *nfrag = fragments of the whole stream. */
+ *   rmx_frc_finish       synchronises once; *nfrag = fragments of the whole stream.
+ * Bit 1 of summary[0] tells the other ranks that this block has tickets left to rmx_kpm_resolve:
+ * after rmx_frc_finish, rmx_kpm_status reports flag 128 on EVERY rank if it does on one, so the
+ * ranks resolve (a no-op where nothing is left) and scan again together. */
 int rmx_frc_scan_block(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint32_t n,
                        int first_is_start, int32_t* pos, uint32_t* frag_id, int32_t* summary);
 int rmx_frc_apply_blocks(rmx_ctx* ctx, const int32_t* summaries, uint32_t rank, uint32_t world,

@@ -17,6 +17,10 @@ struct ScanParams {
   uint32_t first_is_start;
   int32_t carry_in[3];  // the carry on entry (by value: no upload)
   int32_t* summary;     // optional, device: the block's scan summary [has a start, x, y, starts] (out)
+  // with a summary: the matcher's status word — bit 128 (tickets left to rmx_kpm_resolve) travels
+  // as bit 1 of summary[0], so that every rank of a sharded stream learns that SOME rank has to
+  // resolve and all of them derive the positions again together
+  const uint32_t* kpm_status;
 };
 
 // Summary of a run of frames: did it contain a fragment start, the position offset since the
@@ -117,7 +121,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
     p.carry[1] = s_carry.y;
     p.carry[2] = s_carry.c;
     if (p.summary) {
-      p.summary[0] = (p.first_is_start || s_carry.c > 0) ? 1 : 0;
+      p.summary[0] = ((p.first_is_start || s_carry.c > 0) ? 1 : 0) | ((p.kpm_status && (*p.kpm_status & 128u)) ? 2 : 0);
       p.summary[1] = s_carry.x;
       p.summary[2] = s_carry.y;
       p.summary[3] = s_carry.c;
@@ -134,15 +138,16 @@ struct ApplyParams {
   const int32_t* summaries;  // world x 4
   int32_t* pos;
   uint32_t* frag;
-  uint32_t* nfrag_out;  // fragments of the whole stream
+  uint32_t* nfrag_out;  // fragments of the whole stream; [1]: some block has tickets left to rmx_kpm_resolve
   uint32_t n, rank, world;
 };
 __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
   int32_t ax = 0, ay = 0;
-  uint32_t ac = 0, all = 0;
+  uint32_t ac = 0, all = 0, pending = 0;
   for (uint32_t q = 0; q < p.world; ++q) {  // (world is small; every thread folds for itself)
-    const int32_t r = p.summaries[4 * q], x = p.summaries[4 * q + 1], y = p.summaries[4 * q + 2];
+    const int32_t r = p.summaries[4 * q] & 1, x = p.summaries[4 * q + 1], y = p.summaries[4 * q + 2];
     const uint32_t c = (uint32_t)p.summaries[4 * q + 3];
+    pending |= (uint32_t)p.summaries[4 * q] & 2u;
     if (q < p.rank) {
       ax = r ? x : ax + x;
       ay = r ? y : ay + y;
@@ -150,7 +155,10 @@ __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
     }
     all += c;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *p.nfrag_out = all + 1;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    p.nfrag_out[0] = all + 1;
+    p.nfrag_out[1] = pending;
+  }
   for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < p.n; i += gridDim.x * 256) {
     const uint32_t fl = p.frag[i];
     if (fl == 0) {

@@ -102,6 +102,7 @@ def fold_block_summaries(summaries, rank):
     ax = ay = ac = 0
     for q in range(rank):
         r, x, y, c = (int(v) for v in summaries[q])
+        r &= 1  # (bit 1: the block has tickets left to rmx_kpm_resolve)
         ax, ay = (x, y) if r else (ax + x, ay + y)
         ac += c
     return (ax, ay), ac
@@ -227,14 +228,22 @@ class Aligner:
                 _, maxk = ctx.kpe_status()
                 raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
             rc, fl = ctx.kpm_status()
-            if rc == L.RMX_ERR_CAPACITY and fl == 128 and self.world == 1:
+            if rc == L.RMX_ERR_CAPACITY and fl == 128:
                 # regions / pairs the LDS matcher left to its global-memory instance (a frame with
                 # thousands of keypoints in one region): tickets computed there, offsets rewritten,
-                # positions derived again.  (Sharded streams: the ranks would have to agree on taking
-                # this path before their collectives — not wired, the error below is raised instead.)
+                # positions derived again.  On a sharded stream every rank gets here if one does
+                # (the flag travels with the scan summaries), so the collectives below pair up.
                 ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
-                pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
-                out.update(pos=pos, frag=frag, nfrag=carry[1] + 1)
+                if self.world == 1:
+                    pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
+                    nfrag = carry[1] + 1
+                else:
+                    pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
+                    summ = _all_gather_flat(mine, self.world, self.dist, self.group)
+                    ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
+                    nfrag = ctx.frc_finish()
+                    ctx.kpm_status()  # (the flag of the first pass, gathered again)
+                out.update(pos=pos, frag=frag, nfrag=nfrag)
             elif rc:
                 raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
         if compress:

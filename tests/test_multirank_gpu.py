@@ -140,3 +140,64 @@ def test_four_ranks_equal_single_process_bit_for_bit(gpu):
         assert np.array_equal(pos, want["pos"][lo:hi]) and np.array_equal(frag, want["frag"][lo:hi]), rank
         assert np.array_equal(pos_all, want["pos"]) and np.array_equal(frag_all, want["frag"]), rank
         assert nf == nfrag
+
+
+def _huge_region_stream():
+    from remap_amd.synth import scroller_v1
+
+    frames, _ = scroller_v1(40, dens=120)
+    frames = frames.copy()
+    rng = np.random.default_rng(4)
+    big = np.full((240, 320), 6, np.uint8)
+    big[6:126, 6:86] = rng.integers(0, 16, (120, 80))  # ~6 000 keypoints in grid region 0
+    frames[31] = big
+    frames[32] = np.roll(big, -3, axis=1)
+    return frames
+
+
+def _worker_resolve(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    from remap_amd.pipeline import Aligner, shard_range
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frames = _huge_region_stream()
+    n = len(frames)
+    lo, hi = shard_range(n, rank, world)
+    al = Aligner(320, 240, kmax=16384, dist=dist)
+    out = al.align(torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda(), n_total=n)
+    q.put((rank, lo, hi, out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy(), out["pos"].cpu().numpy(),
+           out["frag"].cpu().numpy(), out["nfrag"]))
+    al.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_ranks_resolve_a_huge_region_together(gpu):
+    """Only rank 1's block holds frames with more than 4 096 keypoints in one grid region.  The
+    flag travels with the scan summaries: both ranks take the resolve-and-scan-again path (a
+    no-op on rank 0), their collectives pair up, and the result equals the oracle's."""
+    import torch.multiprocessing as mp
+
+    import orclib as O
+
+    frames = _huge_region_stream()
+    o = O.orc_frc(frames)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_resolve, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=500) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, lo, hi, dxdy, matched, pos, frag, nf in res:
+        assert np.array_equal(matched, o["matched"][lo:hi]) and np.array_equal(dxdy, o["dxdy"][lo:hi]), rank
+        assert np.array_equal(pos, o["pos"][lo:hi]) and np.array_equal(frag, o["frag"][lo:hi]), rank
+        assert nf == int(o["frag"].max()) + 1
