@@ -68,7 +68,8 @@ typedef struct rmx_ctx rmx_ctx;
 /* Replaces the construction of kpe::extractor<Grid,Overlap>{dims} (kpe.hpp:84-90) and of
  * frc::collector{dims} (frc.hpp:51-53): fixes frame width/height, the region grid
  * (4x2 overlap 16 for frc.hpp:22-26, 1x1 overlap 0 for fgs.hpp:17,85) and the stride
- * (kmax rows) of per-frame descriptor tables.  `stream` is a hipStream_t passed as
+ * (kmax rows, 1 .. 4 194 304; rmx_kpm_seq takes contexts up to 16 384) of per-frame
+ * descriptor tables.  `stream` is a hipStream_t passed as
  * void* (NULL = the device's default stream). */
 int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
                    uint32_t grid_h, uint32_t overlap, uint32_t kmax, void* stream,
@@ -233,7 +234,10 @@ int rmx_fgm_blend(rmx_ctx* ctx, const uint16_t* canvas, uint32_t canvas_w,
  *   dims   : nfrag*2 uint32 HOST (width, height)
  *   pairs  : npairs*2 uint32 HOST (previous index, current index)
  *   votes  : npairs rmx_vote HOST out
- * Synchronises. */
+ * Fragments of any size: pairs of two fragments with at most `kmax` keypoints (the context's,
+ * at most 4 096) are matched out of LDS tables; larger ones, and pairs with more distinct
+ * offsets than those hold, out of tables in device memory the call allocates (up to 5 967 347
+ * keypoints per fragment and 2^31 point pairs per pair).  Synchronises. */
 int rmx_kpm_cell_pairs(rmx_ctx* ctx, const rmx_desc* const* tables,
                        const uint32_t* kcounts, const uint8_t* const* masks,
                        const uint32_t* dims, uint32_t nfrag, const uint32_t* pairs,
