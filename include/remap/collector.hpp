@@ -210,10 +210,10 @@ public:
   // frames staged per device block (a block of 320x240 frames is 75 KB/frame of HBM x3)
   static inline constexpr std::uint32_t block_frames = 4096;
   // rows per descriptor table to start with; a frame with more keypoints makes the collector
-  // re-run its block with larger tables (the reference has no limit, kpr.hpp:121-124), up to
-  // the matcher's table stride
+  // re-run its block with larger tables (the reference has no limit, kpr.hpp:121-124) — a frame
+  // cannot have more keypoints than pixels
   static inline constexpr std::uint32_t kmax = 2048;
-  static inline constexpr std::uint32_t max_kmax = 16384;
+  static inline constexpr std::uint32_t max_kmax = 1u << 22;
 
   collector(mrl::dimensions_t d)
       : dim_{d}, ctx_{remap::context_cache::get(std::uint32_t(d.width_), std::uint32_t(d.height_), 4, 2, 16, kmax)} {}
@@ -426,7 +426,8 @@ private:
     current_id_ = id;
   }
   // A frame had `need` keypoints: switch to a context whose tables hold them (power of two,
-  // at most max_kmax); the halo table moves to the new stride.
+  // at most max_kmax); the halo table moves to the new stride.  (Above 16 384 rows the tables of
+  // a 4 096-frame block take gigabytes — 288 GB of HBM are there for that.)
   void grow_tables(std::uint32_t need, bool have_halo) {
     std::uint32_t k = kmax_;
     while (k < need) k <<= 1;

@@ -68,8 +68,7 @@ typedef struct rmx_ctx rmx_ctx;
 /* Replaces the construction of kpe::extractor<Grid,Overlap>{dims} (kpe.hpp:84-90) and of
  * frc::collector{dims} (frc.hpp:51-53): fixes frame width/height, the region grid
  * (4x2 overlap 16 for frc.hpp:22-26, 1x1 overlap 0 for fgs.hpp:17,85) and the stride
- * (kmax rows, 1 .. 4 194 304; rmx_kpm_seq takes contexts up to 16 384) of per-frame
- * descriptor tables.  `stream` is a hipStream_t passed as
+ * (kmax rows, 1 .. 4 194 304) of per-frame descriptor tables.  `stream` is a hipStream_t passed as
  * void* (NULL = the device's default stream). */
 int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
                    uint32_t grid_h, uint32_t overlap, uint32_t kmax, void* stream,
@@ -141,8 +140,8 @@ int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint
 int rmx_kpm_status(rmx_ctx* ctx, uint32_t* flags);
 
 /* The tickets rmx_kpm_seq left to the global-memory instance of the matcher: a region of a frame
- * with more than 4 096 entries, or a (pair, region) with more shared codes / distinct offsets
- * than the LDS instances hold (rmx_kpm_status then returns RMX_ERR_CAPACITY with flag bit 128
+ * with more than 4 096 entries, a frame with more than 16 384 keypoints, or a (pair, region) with
+ * more shared codes / distinct offsets than the LDS instances hold (rmx_kpm_status then returns RMX_ERR_CAPACITY with flag bit 128
  * and no other bit).  Computes them (same arguments as the rmx_kpm_seq call they belong to),
  * re-runs declare (kpm.hpp:199-211) and rewrites dxdy / matched; *resolved (may be NULL) =
  * number of tickets.  Positions derived from the old dxdy / matched (rmx_frc_scan) must be

@@ -308,7 +308,8 @@ struct KpmBuildParams {
   const uint32_t* halo_kcount;
   uint32_t* pool;
   uint32_t* status;
-  uint32_t n, kmax, nreg;
+  uint32_t n, kmax, nreg;  // kmax: rows per frame the pool is laid out for (<= KPM_TABLE_MAX)
+  uint32_t tstride;        // rows between two frames' tables in desc (>= kmax; 0 = kmax)
   // work list of the global-memory matcher (rmx_kpm_resolve): (pair * nreg + region) items whose
   // tickets the LDS instances cannot compute; null = report an overflow as a capacity error
   uint32_t* big;
@@ -397,7 +398,7 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
 
   // fslot: 0..n-1 frames of the batch, n = halo
   const bool is_halo = fslot == p.n;
-  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * (p.tstride ? p.tstride : p.kmax);
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
   if (needs_large && needs_large[fslot] != 3u) return;  // built by the wave-per-region kernels (uniform)
@@ -596,8 +597,17 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   __shared__ uint32_t s_big, s_maxe;
 
   const bool is_halo = fslot == p.n;
-  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * (p.tstride ? p.tstride : p.kmax);
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
+  if (FIRST && k > p.kmax && p.big) {
+    // more keypoints than the pool is laid out for (a frame that is mostly noise): all eight
+    // regions are left empty here; tier 5 = kpm_build hands the tickets of the frame's two pairs
+    // to rmx_kpm_resolve, whose tables have no size limit (not from this kernel: its first
+    // workgroup is still clearing the lists' counters)
+    if (threadIdx.x < 8 * 8) (p.pool + (size_t)fslot * kpm_stride_u32(p.kmax))[threadIdx.x] = 0;
+    if (threadIdx.x == 0) needs_large[fslot] = 5u;
+    return;
+  }
   if (k > p.kmax) k = p.kmax;
   const uint32_t lane = threadIdx.x & (LPR - 1u);  // lane inside the region's group
   const uint32_t r = LPR == 64 ? (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : threadIdx.x / LPR;
@@ -787,7 +797,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
 
   if (tier[fslot] != TIN) return;  // uniform: built already, or not yet examined
   const bool is_halo = fslot == p.n;
-  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * p.kmax;
+  const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * (p.tstride ? p.tstride : p.kmax);
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
   if (k > p.kmax) k = p.kmax;
   const uint32_t lane = threadIdx.x & 63u;
@@ -964,6 +974,20 @@ __device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want
 template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
 __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large, uint32_t nslots) {
   kpm_for_tier(needs_large, 3u, nslots, [&](uint32_t fslot) { kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot); });
+  if (p.big)  // tier 5: frames beyond the pool's layout (kpm_build_small_frame)
+    kpm_for_tier(needs_large, 5u, nslots, [&](uint32_t fslot) {
+      if (threadIdx.x == 0) {
+        const bool is_halo = fslot == p.n;
+        const uint32_t q0 = is_halo ? 0u : fslot;
+        const bool two = !is_halo && fslot + 1 < p.n;
+        const uint32_t at = atomicAdd(&p.big[0], two ? 2u * p.nreg : p.nreg);
+        for (uint32_t r = 0; r < p.nreg; ++r) {
+          p.big[1 + at + r] = q0 * p.nreg + r;
+          if (two) p.big[1 + at + p.nreg + r] = (fslot + 1) * p.nreg + r;
+        }
+        atomicOr(&p.status[1], 128u);
+      }
+    });
 }
 // tier 4: a wave per region, up to 64 entries per region
 __global__ __launch_bounds__(512) void kpm_build_small64(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
@@ -988,6 +1012,7 @@ struct KpmMatchParams {
   uint32_t has_halo;
   uint32_t weight_switch;
   uint32_t* big;       // items left to rmx_kpm_resolve by the last tier (same layout)
+  uint32_t tstride;    // rows between two frames' tables in desc (0 = kmax)
 };
 
 __device__ __forceinline__ uint32_t off_key(int32_t dx, int32_t dy) {
@@ -1116,8 +1141,9 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   const uint32_t pslot = q == 0 ? p.n : q - 1;
   const uint32_t* P = p.pool + (size_t)pslot * stride;
   const uint32_t* Cc = p.pool + (size_t)q * stride;
-  const rmx_desc* pdesc = q == 0 ? p.halo_desc : p.desc + (size_t)(q - 1) * p.kmax;
-  const rmx_desc* cdesc = p.desc + (size_t)q * p.kmax;
+  const uint32_t tstride = p.tstride ? p.tstride : p.kmax;
+  const rmx_desc* pdesc = q == 0 ? p.halo_desc : p.desc + (size_t)(q - 1) * tstride;
+  const rmx_desc* cdesc = p.desc + (size_t)q * tstride;
   const uint32_t* ph = P + r * 8;
   const uint32_t* ch = Cc + r * 8;
   const uint32_t Gc = ch[H_G];

@@ -78,6 +78,19 @@ def test_collector_resolves_huge_regions(gpu, tmp_path):
     check_collect(exe, frames, tmp_path)
 
 
+def test_collector_takes_frames_of_pure_noise(gpu, tmp_path):
+    """~46 000 keypoints per frame: the collector grows its tables to 65 536 rows, the matcher
+    hands such frames to its global-memory instance — collect never refuses a frame."""
+    exe = build_driver(str(tmp_path))
+    frames, _ = scroller_v1(10, dens=100)
+    frames = frames.copy()
+    rng = np.random.default_rng(33)
+    noise = rng.integers(0, 16, size=(240, 320), dtype=np.uint8)
+    frames[4] = noise
+    frames[5] = np.roll(noise, -3, axis=1)
+    check_collect(exe, frames, tmp_path)
+
+
 def check_collect(exe, frames, tmp_path):
     blob = tmp_path / "frames.bin"
     frames.tofile(blob)

@@ -258,6 +258,47 @@ def test_grid_matcher_regions_beyond_the_lds_instances(gpu):
     ctx.close()
 
 
+def test_grid_matcher_frames_beyond_16384_keypoints(gpu):
+    """Pure-noise frames: ~46 000 keypoints each, more than the 16 384 rows the matcher's pool is
+    laid out for — such a frame is left empty there and all eight tickets of its two pairs are
+    computed by the global-memory instance (tables of kmax = 65 536 rows from kpe_table_big)."""
+    import torch
+
+    frames, _ = scroller_v1(8, dens=100)
+    frames = frames.copy()
+    rng = np.random.default_rng(12)
+    noise = rng.integers(0, 16, size=(240, 320), dtype=np.uint8)
+    frames[3] = noise
+    frames[4] = np.roll(noise, -2, axis=1)
+    frames[5] = np.roll(noise, -4, axis=1)
+    assert O.orc_kpe(noise)[2] > 16384
+    n, H, W = frames.shape
+    ctx = L.Context(W, H, kmax=65536)
+    d = torch.from_numpy(frames).cuda()
+    med, desc, kc = ctx.kpe(d)
+    assert ctx.kpe_status()[0] == 0
+    dxdy, matched = ctx.kpm_seq(desc, kc)
+    rc, fl = ctx.kpm_status()
+    assert rc == L.RMX_ERR_CAPACITY and fl == 128, (rc, fl)
+    assert ctx.kpm_resolve(desc, kc, dxdy, matched) >= 32
+    pos, frag, carry = ctx.frc_scan(dxdy, matched)
+    o = O.orc_frc(frames)
+    assert np.array_equal(dxdy.cpu().numpy(), o["dxdy"]) and np.array_equal(matched.cpu().numpy(), o["matched"])
+    assert np.array_equal(pos.cpu().numpy(), o["pos"]) and np.array_equal(frag.cpu().numpy(), o["frag"])
+    assert matched.cpu().numpy()[4] == 1 and tuple(dxdy.cpu().numpy()[4]) == (2, 0)
+    tickets = ctx.kpm_tickets(n)
+    tabs = L.desc_to_numpy(desc, kc)
+    for q in (3, 4, 6):
+        m, dd, t = O.orc_kpm_grid(tabs[q - 1], tabs[q])
+        for r in range(8):
+            for j in range(3):
+                a, b = tickets[q, r, j], t[r, j]
+                assert int(a["valid"]) == int(b["valid"]), (q, r, j)
+                if int(b["valid"]):
+                    assert (int(a["dx"]), int(a["dy"]), int(a["count"])) == (int(b["dx"]), int(b["dy"]), int(b["count"])), (q, r, j)
+    ctx.close()
+
+
 def test_aligner_resolves_huge_regions_by_itself(gpu):
     import torch
 
