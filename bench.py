@@ -14,9 +14,11 @@ tables and per-frame offsets are all-gathered over RCCL, and the result is the g
 alignment.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     — kpe_main (the dominant kernel): algorithmic bytes (2*W*H + 18*K per frame,
-                 SURVEY.md §8d) / its average launch time from HIP events on the launch
-                 stream, against the 8 TB/s HBM peak;
+  roofline     — kpe_mf (the dominant kernel: keypoint extraction, streaming pass and 5x5 finish
+                 in one launch): algorithmic bytes (2*W*H + 18*K per frame) / its
+                 average launch time from HIP events on the launch stream, against the 8 TB/s HBM
+                 peak; `pair` = the two-kernel form of rounds 1-2a (kpe_main + kpe_finish) timed
+                 on the same box for reference (its kpe_main alone is what round 1 reported);
   cpu_baseline — the reference's own frc::collector::collect (oracle/_ref, built from
                  /root/reference by oracle/build_ref.sh) or, if that library is absent, the
                  CPU restatement (oracle/), timed on one host core on the same frames.
@@ -76,12 +78,12 @@ VALU_RATE_PER_NS = 558.0  # wave-instructions per ns, whole chip: v_min3/med3/ma
 
 
 def pmc_valu(n_local, dens):
-    """VALU wave-instructions of one kpe_main launch from the same committed PMC passes."""
+    """VALU wave-instructions of one kpe_mf launch from the same committed PMC passes."""
     if n_local != FRAMES_PER_GPU or dens != DENS:
         return None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_main.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_mf.json")))
     try:
         return float(json.load(open(files[-1]))["counters_mean_per_launch"]["SQ_INSTS_VALU"])
     except Exception:
@@ -89,15 +91,15 @@ def pmc_valu(n_local, dens):
 
 
 def pmc_traffic(n_local, dens):
-    """HBM bytes per kpe_main launch from the committed rocprofv3 --pmc passes of this same
-    workload (profiles/*_pmc_kpe_main.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py:
+    """HBM bytes per kpe_mf launch from the committed rocprofv3 --pmc passes of this same
+    workload (profiles/*_pmc_kpe_mf.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py:
     FETCH_SIZE doubled, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM).  None if the workload
     differs from the profiled one (10 000 frames, dens 200) or no profile is committed."""
     if n_local != FRAMES_PER_GPU or dens != DENS:
         return None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_main.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_mf.json")))
     if not files:
         return None
     try:
@@ -203,14 +205,22 @@ def main():
     dx2, mt2, ps2, fg2 = (out[k].cpu().numpy() for k in ("dxdy", "matched", "pos", "frag"))
     exact = bool(exact and mt2[first:].all() and (dx2[first:] == truth[lo + first:hi]).all()
                  and (ps2[:, 0] == cam_x[lo:hi]).all() and (ps2[:, 1] == 0).all() and (fg2 == 0).all() and nfrag_timed == 1)
-    ms_kpe = al.ctx.kernel_ms("kpe_main")          # average per launch
+    ms_kpe = al.ctx.kernel_ms("kpe_main")          # average per launch (the timing track of kpe_mf / kpe_main)
     launches_per_step = al.ctx.kernel_launches("kpe_main") / max(1, args.steps)
     al.ctx.set_timing(True)
     for _ in range(3):
         al.align(frames, n_total=n_total)
     # per-step totals of the other kernels (kpm_build / kpm_match run several instances each)
     ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3
-                for k in ("kpe_finish", "kpe_table", "kpm_build", "kpm_match")}
+                for k in ("kpe_table", "kpm_build", "kpm_match")}
+    # the two-kernel form (rounds 1-2a), same box, untimed part: kpe_main + kpe_finish
+    os.environ["RMX_KPE_PAIR"] = "1"
+    al.align(frames, n_total=n_total)
+    al.ctx.set_timing(True)
+    for _ in range(3):
+        al.align(frames, n_total=n_total)
+    pair = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3 for k in ("kpe_main", "kpe_finish")}
+    del os.environ["RMX_KPE_PAIR"]
     al.ctx.set_timing(False)
 
     # tier B: + fgm blit into the fragment canvases (reported beside the headline)
@@ -276,8 +286,8 @@ def main():
         achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
         traffic = pmc_traffic(n_local, args.dens) if launches_per_step == 1 else None
         valu = pmc_valu(n_local, args.dens) if launches_per_step == 1 else None
-        # what actually bounds kpe_main: ~52 integer VALU ops per 4 pixels against
-        # the chip's measured VALU issue rate; reported beside the contract's HBM figure
+        # what actually bounds the kernel: its VALU instruction count against the
+        # chip's measured VALU issue rate; reported beside the contract's HBM figure
         valu_floor_ms = valu / VALU_RATE_PER_NS * 1e-6 if valu else None
         line = {
             "metric": "aligned frames/s, 320x240 stream (kpe+kpm+frc: alignment only, no canvas blit), offsets bit-exact",
@@ -301,9 +311,16 @@ def main():
             "frames_per_s_with_blit": n_total * nb / dtb,
             "frames_per_s_with_blit_and_codec": n_total * nb / dtc,
             "frames_per_s_host_fed": n_total * nh / dth,
-            "kernel_ms": dict(kpe_main=ms_kpe, **ms_parts),
+            "kernel_ms": dict(kpe_mf=ms_kpe, **ms_parts),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "kpe_main",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "kpe_mf (whole keypoint extraction: streaming 3x3 pass + 5x5 finish of the workgroup's own "
+                                   "candidates; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "pair": {"note": "two-kernel form of rounds 1-2a on this box, same algorithmic bytes",
+                                  "kpe_main_ms": pair["kpe_main"], "kpe_finish_ms": pair["kpe_finish"],
+                                  "kpe_main_alone_frac": alg_bytes / (pair["kpe_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS if pair["kpe_main"] > 0 else None,
+                                  "both_frac": alg_bytes / ((pair["kpe_main"] + pair["kpe_finish"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                  if pair["kpe_main"] > 0 else None},
                          "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
                          "torch_device_copy_gbs": torch_copy_gbs,
                          "valu_wave_instructions": valu, "valu_floor_ms": valu_floor_ms,

@@ -297,7 +297,8 @@ void rmx_luts(uint8_t native_to_ordered[16], uint8_t ordered_to_native[16]);
 /* Kernel timing with HIP events recorded on the context stream around each launch (no host
  * synchronisation while recording).  rmx_set_timing(ctx, 1) opens a measurement window (and
  * drops earlier samples); rmx_last_kernel_ms synchronises the stream and returns the AVERAGE
- * duration in milliseconds of `kernel` ("kpe_main", "kpe_finish", "kpe_table", "kpm_build", "kpm_match",
+ * duration in milliseconds of `kernel` ("kpe_main" = the extraction kernel: kpe_mf, or kpe_main of the
+ * two-kernel form whose second half is "kpe_finish"; "kpe_table", "kpm_build", "kpm_match",
  * "fgm_blit", "nic_compress", "fdf") over the launches of the window (0 if none).  An event pair
  * costs ~10 us of stream time per launch on this hardware: enabled = 2 records only
  * "kpe_main" (what bench.py uses inside its timed region), 0 switches recording off. */

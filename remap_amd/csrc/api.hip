@@ -536,14 +536,24 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     p.HB = (ctx->H + 7) / 8;
     p.cand = ctx->cand + (size_t)f0 * p.HB * p.Wd;
     dim3 grid((p.groups + 3) / 4, (ctx->H + rps - 1) / rps);
+    // one kernel for both halves (kpe_mf) unless asked for the pair (experiments) or the strip is
+    // longer than its LDS words hold
+    const bool one_kernel = !overlap && rps <= 8 * KPE_WPS_MAX && getenv("RMX_KPE_PAIR") == nullptr;
     {
       Timer t(ctx, &ctx->ms_kpe);
-      if (ctx->W % 4 == 0)
+      if (one_kernel) {
+        if (ctx->W % 4 == 0)
+          hipLaunchKernelGGL(kpe_mf<true>, grid, dim3(256), 0, ctx->stream, p);
+        else
+          hipLaunchKernelGGL(kpe_mf<false>, grid, dim3(256), 0, ctx->stream, p);
+      } else if (ctx->W % 4 == 0) {
         hipLaunchKernelGGL(kpe_main<true>, grid, dim3(256), 0, ctx->stream, p);
-      else
+      } else {
         hipLaunchKernelGGL(kpe_main<false>, grid, dim3(256), 0, ctx->stream, p);
+      }
     }
     RMX_HIP(hipGetLastError());
+    if (one_kernel) continue;
     const uint32_t cpf = (p.HB * p.Wd + FIN_WORDS - 1) / FIN_WORDS;
     if (overlap) {
       RMX_HIP(hipEventRecord(ctx->ev_main[sub_idx], ctx->stream));

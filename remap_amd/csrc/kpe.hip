@@ -125,10 +125,18 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 // ALIGNED = frame width is a multiple of 4.  Otherwise rows start at unaligned bytes (the
 // loads simply are unaligned dwords), the last dword column of a row is partial, and its
 // median bytes are stored one by one so the next row's first pixels are not overwritten.
-template <bool ALIGNED>
-__global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
+constexpr uint32_t KPE_WPS_MAX = 6;  // 8-row blocks per strip a workgroup of kpe_mf keeps in LDS (strips of <= 48 rows)
+
+// The streaming pass.  LDS_CAND = false: kpe_main (candidate words to the plane in HBM);
+// true: kpe_mf (candidate words to s_c[8-row block of the strip][thread]).  f_out / c_out /
+// ok_out: the lane's frame, dword column and whether it owns one (not a halo lane).
+template <bool ALIGNED, bool LDS_CAND>
+__device__ __forceinline__ void kpe_main_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t& f_out, uint32_t& c_out, bool& ok_out) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  ok_out = false;
+  f_out = 0;
+  c_out = 0;
 
   // XCD-aware block remap (bijective): blocks that share an XCD get neighbouring groups.
   const uint32_t nb = gridDim.x, bid = blockIdx.x;
@@ -157,6 +165,9 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   const rsrc_t rcand = make_rsrc(p.cand + (size_t)f0 * p.HB * p.Wd, 0x7fffffffu);
   const uint32_t voff_st = lane_ok ? voff : 0xffffffffu;  // dropped by the range check
   const uint32_t voff_c = lane_ok ? ((f - f0) * p.HB * p.Wd + c) * 4 : 0xffffffffu;
+  ok_out = lane_ok;
+  f_out = f;
+  c_out = c;
 
   // per-pixel x validity: processed x in [2, W-3] (kpe.hpp:183-184)
   uint32_t maskx = 0;
@@ -183,7 +194,10 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
     }
   };
   auto store_cand = [&](int yb, uint32_t v) {
-    __builtin_amdgcn_raw_buffer_store_b32(v, rcand, voff_c, (uint32_t)(yb * (int)p.Wd * 4), 0);
+    if (LDS_CAND)
+      s_c[yb - (y0 >> 3)][threadIdx.x] = lane_ok ? v : 0u;
+    else
+      __builtin_amdgcn_raw_buffer_store_b32(v, rcand, voff_c, (uint32_t)(yb * (int)p.Wd * 4), 0);
   };
   // unprocessed border rows of this strip are written 0
   for (int y = y0; y < min(vy0, y1); ++y) store_row(y, 0u);
@@ -237,6 +251,13 @@ __global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
   for (int yb = (vy1 + 7) >> 3; yb * 8 < y1; ++yb) store_cand(yb, 0u);
 }
 
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void kpe_main(KpeParams p) {
+  uint32_t f, c;
+  bool ok;
+  kpe_main_body<ALIGNED, false>(p, nullptr, f, c, ok);
+}
+
 // ---- kernel 2: finish the candidates ---------------------------------------------------------------
 // compute_pixel's second half (kpe.hpp:316-321) + encode_keypoint (kpe.hpp:342-379).
 // A candidate's data moves in two phases so that several candidates per lane can be in
@@ -258,6 +279,8 @@ __device__ __forceinline__ void gather_candidate(const KpeParams& p, uint32_t x,
   }
 }
 
+// MULTI: the lanes of a wave may belong to different frames (kpe_mf); otherwise f is uniform.
+template <bool MULTI = false>
 __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool active,
                                                   const CandData& d) {
   const uint32_t s = (x - 2) & 3u;
@@ -318,12 +341,27 @@ __device__ __forceinline__ void resolve_candidate(const KpeParams& p, uint32_t x
   uint32_t b12 = weight | (e[4] << 4);
   // one atomic per wave for the keypoints of its lanes (f is the workgroup's frame): dense
   // stream 0.81 -> 0.78 ms per 10 000 frames, sparse unchanged
-  uint32_t base = 0;
-  const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(km));
-  if (lane_id() == leader) base = atomicAdd(&p.kcount[f], (uint32_t)__builtin_popcountll(km));
-  base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+  uint32_t slot = 0;
+  if (!MULTI) {
+    uint32_t base = 0;
+    const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(km));
+    if (lane_id() == leader) base = atomicAdd(&p.kcount[f], (uint32_t)__builtin_popcountll(km));
+    base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+    slot = base + mbcnt(km);
+  } else {  // one atomic per wave and distinct frame (a wave spans at most a few)
+    uint64_t todo = km;
+    while (todo) {
+      const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(todo));
+      const uint32_t fl = (uint32_t)__builtin_amdgcn_readlane((int)f, (int)leader);
+      const uint64_t same = __builtin_amdgcn_ballot_w64(kp && f == fl);
+      uint32_t base = 0;
+      if (lane_id() == leader) base = atomicAdd(&p.kcount[fl], (uint32_t)__builtin_popcountll(same));
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+      if (kp && f == fl) slot = base + mbcnt(same);
+      todo &= ~same;
+    }
+  }
   if (kp) {
-    const uint32_t slot = base + mbcnt(km);
     if (slot < p.kmax) {
       RawDesc* dd = p.raw + (size_t)f * p.kmax + slot;
       uint4 c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);
@@ -419,6 +457,98 @@ __global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
     gather_candidate(p, xb, yb, act_b ? f : 0u, db);
     resolve_candidate(p, xa, ya, f, act_a, da);
     if (k0 + 256 < total) resolve_candidate(p, xb, yb, f, act_b, db);
+  }
+}
+
+// ---- one kernel: the streaming pass, then the workgroup's own candidates -------------------------------
+// kpe_finish is bound by its gathers: it re-reads nearly every line of the frames from HBM
+// (817 MB per 10 000 frames), long after kpe_main streamed them.  Here the workgroup that
+// streamed a tile (4 waves x 62 dword columns x one strip of rows) keeps the tile's candidate
+// words in LDS and, after its walk, finishes them itself: the 5x5 windows are gathered while
+// the tile's lines are still in the XCD's L2 / the Infinity Cache (rows of the neighbouring
+// strips included), there is no candidate plane in HBM and no second launch.  Same arithmetic
+// as the pair (kpe_main_body + the hand-out / gather / resolve of kpe_finish).
+template <bool ALIGNED>
+__global__ __launch_bounds__(256) void kpe_mf(KpeParams p) {
+  __shared__ uint32_t s_c[KPE_WPS_MAX][256];
+  __shared__ uint32_t s_f[256], s_col[256];
+  __shared__ uint32_t s_tbase[257];
+  __shared__ uint32_t s_scan[8];
+  const uint32_t tid = threadIdx.x;
+#pragma unroll
+  for (uint32_t k = 0; k < KPE_WPS_MAX; ++k) s_c[k][tid] = 0;
+  {
+    uint32_t f, c;
+    bool ok;
+    kpe_main_body<ALIGNED, true>(p, s_c, f, c, ok);
+    s_f[tid] = ok ? f : 0xffffffffu;
+    s_col[tid] = c;
+  }
+  __syncthreads();
+  const uint32_t wps = p.rows_per_strip >> 3, yb0 = blockIdx.y * wps;
+  uint32_t cnt = 0;
+#pragma unroll
+  for (uint32_t k = 0; k < KPE_WPS_MAX; ++k) cnt += (uint32_t)__builtin_popcount(s_c[k][tid]);
+  const uint32_t lane = tid & 63u, wv = tid >> 6;
+  uint32_t incl = cnt;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  if (lane == 63) s_scan[wv] = incl;
+  __syncthreads();
+  uint32_t wbase = 0, total = 0;
+  for (uint32_t k = 0; k < 4; ++k) {
+    uint32_t sc = s_scan[k];
+    if (k < wv) wbase += sc;
+    total += sc;
+  }
+  s_tbase[tid] = wbase + incl - cnt;
+  if (tid == 0) s_tbase[256] = total;
+  __syncthreads();
+  auto locate = [&](uint32_t k, uint32_t& x, uint32_t& y, uint32_t& f) {
+    uint32_t lo = 0, hi = 256;  // owner thread: largest t with s_tbase[t] <= k
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (s_tbase[mid] <= k)
+        lo = mid;
+      else
+        hi = mid;
+    }
+    uint32_t nth = k - s_tbase[lo], kb = 0, w = s_c[0][lo];
+    for (;;) {  // walk the owner's words
+      uint32_t c = (uint32_t)__builtin_popcount(w);
+      if (nth < c) break;
+      nth -= c;
+      w = s_c[++kb][lo];
+    }
+    uint32_t b = 0;
+#pragma unroll
+    for (uint32_t sft = 16; sft >= 1; sft >>= 1) {
+      uint32_t lowc = (uint32_t)__builtin_popcount(w & ((1u << sft) - 1u));
+      if (nth >= lowc) {
+        nth -= lowc;
+        w >>= sft;
+        b += sft;
+      }
+    }
+    x = s_col[lo] * 4 + (b >> 3);
+    y = (yb0 + kb) * 8 + (b & 7u);
+    f = s_f[lo];
+  };
+  for (uint32_t k0 = 0; k0 < total; k0 += 512) {
+    const uint32_t ka = k0 + tid, kb = k0 + 256 + tid;
+    const bool act_a = ka < total, act_b = kb < total;
+    if (__builtin_amdgcn_ballot_w64(act_a) == 0) break;  // this wave's lanes are past the last candidate (no barriers below)
+    uint32_t xa = 2, ya = 2, fa = 0, xb = 2, yb = 2, fb = 0;
+    if (act_a) locate(ka, xa, ya, fa);
+    if (act_b) locate(kb, xb, yb, fb);
+    CandData da, db;
+    gather_candidate(p, xa, ya, fa, da);
+    gather_candidate(p, xb, yb, fb, db);
+    resolve_candidate<true>(p, xa, ya, fa, act_a, da);
+    if (k0 + 256 < total) resolve_candidate<true>(p, xb, yb, fb, act_b, db);
   }
 }
 

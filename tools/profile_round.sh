@@ -16,8 +16,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 cd $R
 bash tools/pmc_kpe.sh $TAG > $OUT/pmc.log 2>&1 || tail -5 $OUT/pmc.log
-python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_main $OUT/${TAG}_pmc_kpe_main.json > /dev/null
-python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_finish $OUT/${TAG}_pmc_kpe_finish.json > /dev/null
+python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_mf $OUT/${TAG}_pmc_kpe_mf.json > /dev/null
 rm -rf $OUT/stats gpurun_out/pmc_$TAG
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
