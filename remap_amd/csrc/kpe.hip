@@ -66,6 +66,9 @@ __device__ __forceinline__ uint32_t xlane_prev(uint32_t v) { return (uint32_t)__
 __device__ __forceinline__ uint32_t xlane_next(uint32_t v) { return (uint32_t)__shfl_down((int)v, 1); }
 #endif
 
+// row (0..7) of an 8-row block flagged by bit `bb` of a pixel's byte in a candidate word
+__device__ __forceinline__ uint32_t cand_row(uint32_t bb) { return bb < 4u ? 3u - bb : 11u - bb; }
+
 struct RowT {
   uint32_t lo[4], md[4], hi[4];
   uint32_t key;  // the row's 4 keys, packed
@@ -100,8 +103,13 @@ __device__ __forceinline__ uint32_t merge_rows(const RowT& A, const RowT& B, con
     uint32_t c = umed3(A.hi[j], B.hi[j], C.lo[j]);
     r[j] = umed3(a, b, c);
   }
-  uint32_t lo = r[1] << 8 | r[0], hi = r[3] << 8 | r[2];  // v_lshl_or_b32 x3
-  return hi << 16 | lo;
+  // three v_lshl_or_b32 (written out: the compiler turns the expression into two shifts, one
+  // shift-or and a 3-input or)
+  uint32_t lo, hi, pk;
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(lo) : "v"(r[1]), "v"(r[0]));
+  asm("v_lshl_or_b32 %0, %1, 8, %2" : "=v"(hi) : "v"(r[3]), "v"(r[2]));
+  asm("v_lshl_or_b32 %0, %1, 16, %2" : "=v"(pk) : "v"(hi), "v"(lo));
+  return pk;
 }
 
 // [b0|b1<<4, b2|b3<<4] of a dword of four nibble-valued bytes, as a 16-bit value.
@@ -120,8 +128,9 @@ __device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
 
 // ---- kernel 1: streaming pass -------------------------------------------------------------------
 // frames -> median + candidate bit plane (1 bit per pixel: centre != 4th largest of 3x3).
-// Candidate word layout: one dword per (frame, 8-row block yb, dword column c); bit
-// 8*j + ((r + 4) & 7) flags pixel x = 4c + j, y = 8*yb + r.
+// Candidate word: one dword per (frame, 8-row block yb, dword column c); byte j = pixel
+// x = 4c + j, its bit cand_bit(r) = row y = 8*yb + r (rows 0-3 at bits 3..0, rows 4-7 at bits 7..4:
+// the order in which four rows double their way up a nibble, see the row step).
 // ALIGNED = frame width is a multiple of 4.  Otherwise rows start at unaligned bytes (the
 // loads simply are unaligned dwords), the last dword column of a row is partial, and its
 // median bytes are stored one by one so the next row's first pixels are not overwritten.
@@ -215,7 +224,7 @@ __device__ __forceinline__ void kpe_main_body(const KpeParams& p, uint32_t (*s_c
   uint32_t pf0 = load_row(vy0 + 1), pf1 = load_row(min(vy0 + 2, vy1)), pf2 = load_row(min(vy0 + 3, vy1)),
            pf3 = load_row(min(vy0 + 4, vy1)), pf4 = load_row(min(vy0 + 5, vy1)), pf5 = load_row(min(vy0 + 6, vy1));
 
-  uint32_t C = 0;
+  uint32_t C = 0, hold = 0;  // flags of the current group of four rows / of rows 0-3 of the current 8-row block
   // one output row: consume the prefetched row y+1, refill the prefetch slot with row y+7
 #define RMX_STEP(A, B, Cn, PF, R)                                                        \
   {                                                                                      \
@@ -225,9 +234,14 @@ __device__ __forceinline__ void kpe_main_body(const KpeParams& p, uint32_t (*s_c
     uint32_t pk = merge_rows(A, B, Cn);                                                  \
     store_row(yy, pk & maskx);                                                           \
     uint32_t t = ((((pk ^ B.key) & maskx) + 0x0f0f0f0fu) & 0x10101010u);                 \
-    C = (t << 3) | (C >> 1); /* bit 7 of the pixel's byte, older rows move down */    \
-    if (((uint32_t)yy & 7u) == 7u) {                                                     \
-      store_cand(yy >> 3, C);                                                            \
+    C = (C + C) | t; /* full-rate ops only: a row enters at bit 4 of its pixel's byte, */ \
+    if (((uint32_t)yy & 3u) == 3u) { /* four rows fill the high nibble (row k at bit 7-k) */ \
+      if (((uint32_t)yy & 4u) == 0u) {                                                    \
+        hold = C >> 4;                                                                   \
+      } else {                                                                           \
+        store_cand(yy >> 3, hold | C);                                                   \
+        hold = 0;                                                                        \
+      }                                                                                  \
       C = 0;                                                                             \
     }                                                                                    \
   }
@@ -247,7 +261,10 @@ __device__ __forceinline__ void kpe_main_body(const KpeParams& p, uint32_t (*s_c
   if (y + 4 < vy1) RMX_STEP(T1, T2, T0, pf4, 4)
 #undef RMX_STEP
   // last (partial) block of the strip and blocks that hold only border rows
-  if ((vy1 & 7) != 0) store_cand(vy1 >> 3, C >> (8 - (vy1 & 7)));  // the block's last rows are missing: finish the shifts
+  if ((vy1 & 7) != 0) {  // the block's last rows are missing: finish the shifts of the open group, write what there is
+    if ((vy1 & 3) != 0) C <<= 4 - (vy1 & 3);
+    store_cand(vy1 >> 3, (vy1 & 4) ? (hold | C) : ((vy1 & 3) ? C >> 4 : hold));
+  }
   for (int yb = (vy1 + 7) >> 3; yb * 8 < y1; ++yb) store_cand(yb, 0u);
 }
 
@@ -443,7 +460,7 @@ __global__ __launch_bounds__(256) void kpe_finish(KpeParams p) {
     }
     const uint32_t gw = w0 + wi, yb = gw / p.Wd, c = gw - yb * p.Wd;
     x = c * 4 + (b >> 3);
-    y = yb * 8 + (b & 7u);
+    y = yb * 8 + cand_row(b & 7u);
   };
 
   for (uint32_t k0 = 0; k0 < total; k0 += 512) {
@@ -534,7 +551,7 @@ __global__ __launch_bounds__(256) void kpe_mf(KpeParams p) {
       }
     }
     x = s_col[lo] * 4 + (b >> 3);
-    y = (yb0 + kb) * 8 + (b & 7u);
+    y = (yb0 + kb) * 8 + cand_row(b & 7u);
     f = s_f[lo];
   };
   for (uint32_t k0 = 0; k0 < total; k0 += 512) {
