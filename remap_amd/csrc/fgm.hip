@@ -171,10 +171,15 @@ __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
 
 // ---- fgm::fragment::blit(pos, image, …) (fgm.hpp:87-97,176-188) -------------------------------
 // ++canvas[y+py-zy][x+px-zx][pixel] with uint16 wraparound, for a whole batch of frames.
-// Output-centric: a workgroup OWNS a 128x8 tile of the canvas in LDS (32 B per pixel), walks
-// the frames binned to its tile column, and for every frame that covers the tile adds that frame's pixels
-// to its own bins — no atomics, every frame byte is read once (by the tile it lands in),
-// every canvas dot is read and written once.  Bins wrap modulo 2^16 exactly (fgm.hpp:14).
+// Output-centric, counters in REGISTERS: a wave owns 64 canvas columns x R rows, a lane one
+// column of them.  It walks the frames binned to its tile column; of every frame that covers
+// the tile a lane loads its R pixels (one byte each) and counts them in sixteen 4-bit counters
+// per pixel (two dwords: `v_lshlrev_b64` of a one by 4 x colour, two adds).  Every 15 frames
+// the nibbles are folded into 8-bit counters (four dwords per pixel), every 255 frames — and at
+// the end — those into the canvas with its uint16 wraparound (fgm.hpp:14).  No LDS, no atomics,
+// no barriers; every frame byte is read once (by the tile it lands in), every canvas dot is
+// read and written once per 255 covering frames.  Lanes left or right of a frame shift a zero
+// instead of a one: the frame's edges cost nothing per pixel.
 struct BlitParams {
   const uint8_t* frames;
   const uint8_t* mask;   // optional, same layout as frames: pixels with a non-zero byte are not counted (fgm.hpp:71-86)
@@ -184,17 +189,22 @@ struct BlitParams {
   uint32_t n, W, H;
   uint32_t fragment, cw, ch;
   int32_t zx, zy;
-  uint32_t tiles_x;
-  // frames binned by the tile COLUMNS they overlap (built by blit_bin_* below)
-  uint32_t* col_cnt;   // tiles_x + 1: counts, then exclusive offsets (in place)
-  uint32_t* col_cur;   // tiles_x fill cursors
-  uint32_t* col_list;  // frame ids, <= n * (W / 128 + 2)
+  uint32_t tiles_x;   // 64-pixel tile columns
+  uint32_t groups_x;  // 256-pixel groups of four tile columns (one workgroup's waves)
+  // frames binned by the GROUPS they overlap (built by blit_bin_* below): the four waves of a
+  // workgroup walk the same list in the same order, each skipping what misses its own tile
+  uint32_t* col_cnt;  // groups_x + 1: counts, then exclusive offsets (in place)
+  uint32_t* col_cur;  // groups_x fill cursors
+  uint4* col_list;    // (frame, canvas x, canvas y, -) records, <= n * (W / 256 + 2)
 };
 
-constexpr int BL_TW = 128, BL_TH = 8;
+constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
+// rows of a wave's tile and frames in its pipe (measured: 8 x 2..8 and 4 x 4..8 within 3 %, 16 rows slower);
+// the byte-per-lane kernel for narrow frames holds two frames of 4 rows in registers
+constexpr int BL_ROWS = 8, BL_DEPTH = 4, BL_ROWS_NARROW = 4;
 
-// A frame overlaps at most W/128 + 2 tile columns; three tiny passes bin the batch's frames
-// by tile column so that a tile walks ~(W + 128) / (mean step) frames instead of all n.
+// A frame overlaps at most W/256 + 2 groups; three tiny passes bin the batch's frames by
+// group so that a tile walks ~(W + 256) / (mean step) frames instead of all n.
 // counter[t] += 1 for every active lane, one atomic per distinct t in the wave (neighbouring
 // frames fall into the same few columns); returns the lane's own slot (old value + rank).
 __device__ __forceinline__ uint32_t wave_claim(uint32_t* counter, int t, bool active) {
@@ -220,14 +230,14 @@ __global__ __launch_bounds__(256) void blit_bin_count(BlitParams p) {
   int t0 = 0, t1 = -1;
   if (live) {
     const int ax = p.pos[2 * f] - p.zx;
-    t0 = max(ax, 0) / BL_TW;
-    t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+    t0 = max(ax, 0) / BL_GW;
+    t1 = min((ax + (int)p.W - 1) / BL_GW, (int)p.groups_x - 1);
   }
   for (int k = 0; __builtin_amdgcn_ballot_w64(t0 + k <= t1) != 0; ++k) wave_claim(p.col_cnt, t0 + k, t0 + k <= t1);
 }
 __global__ __launch_bounds__(1024) void blit_bin_scan(BlitParams p) {
   __shared__ uint32_t part[1024];
-  const uint32_t tid = threadIdx.x, n = p.tiles_x;
+  const uint32_t tid = threadIdx.x, n = p.groups_x;
   const uint32_t chunk = (n + 1023) / 1024, i0 = min(n, tid * chunk), i1 = min(n, i0 + chunk);
   uint32_t s = 0;
   for (uint32_t i = i0; i < i1; ++i) s += p.col_cnt[i];
@@ -254,146 +264,355 @@ __global__ __launch_bounds__(1024) void blit_bin_scan(BlitParams p) {
 __global__ __launch_bounds__(256) void blit_bin_fill(BlitParams p) {
   const uint32_t f = blockIdx.x * 256 + threadIdx.x;
   const bool live = f < p.n && !(p.frag_id && p.frag_id[f] != p.fragment);
-  int t0 = 0, t1 = -1;
+  int t0 = 0, t1 = -1, ax = 0, ay = 0;
   if (live) {
-    const int ax = p.pos[2 * f] - p.zx;
-    t0 = max(ax, 0) / BL_TW;
-    t1 = min((ax + (int)p.W - 1) / BL_TW, (int)p.tiles_x - 1);
+    ax = p.pos[2 * f] - p.zx;
+    ay = p.pos[2 * f + 1] - p.zy;
+    t0 = max(ax, 0) / BL_GW;
+    t1 = min((ax + (int)p.W - 1) / BL_GW, (int)p.groups_x - 1);
   }
   for (int k = 0; __builtin_amdgcn_ballot_w64(t0 + k <= t1) != 0; ++k) {
     const bool act = t0 + k <= t1;
     const uint32_t at = wave_claim(p.col_cur, t0 + k, act);
-    if (act) p.col_list[at] = f;
+    if (act) p.col_list[at] = make_uint4(f, (uint32_t)ax, (uint32_t)ay, 0u);
   }
-}
-
-__device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
-  return ((a + b) & 0xffffu) | (((a >> 16) + (b >> 16)) << 16);
 }
 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t blit_rsrc(const uint8_t* base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), (short)0, (int)bytes, 0x00020000);
 }
 
+// nibble (c & 15) of the 64-bit counter word (lo, hi) += one.  v_lshlrev_b64 takes the low six
+// bits of its shift operand, so c << 2 needs no mask; no nibble overflows before the fold (15
+// increments at most), so the two halves add independently.
+__device__ __forceinline__ void blit_count(uint32_t& lo, uint32_t& hi, uint32_t c, uint32_t one) {
+  uint64_t inc;
+  const uint64_t o64 = one;
+  asm("v_lshlrev_b64 %0, %1, %2" : "=v"(inc) : "v"(c << 2), "v"(o64));
+  lo += (uint32_t)inc;
+  hi += (uint32_t)(inc >> 32);
+}
+
+typedef unsigned short blit_us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(blit_us2, a) + __builtin_bit_cast(blit_us2, b));
+}
+
+// R rows x (two nibble words + four byte words) of counters of one lane's canvas column
+template <int R>
+struct BlitCounters {
+  uint32_t nib[R][2], byt[R][4];
+  uint32_t in_nib, in_byt;  // frames counted since the last fold (uniform)
+
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      nib[r][0] = nib[r][1] = 0;
+      byt[r][0] = byt[r][1] = byt[r][2] = byt[r][3] = 0;
+    }
+    in_nib = in_byt = 0;
+  }
+  __device__ __forceinline__ void add(int r, uint32_t c, uint32_t one) { blit_count(nib[r][0], nib[r][1], c, one); }
+  __device__ __forceinline__ void fold_canvas(const BlitParams& p, int X, int Y0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int Y = Y0 + r;
+      if (Y < (int)p.ch && X < (int)p.cw) {
+        uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)X) * 8);
+        uint4 a = dst[0], c = dst[1];
+        // dword k of a dot = bins 2k (low half) and 2k+1 (high half); byt[r][0/1] hold the even/odd
+        // colours 0..7, byt[r][2/3] those of 8..15, one byte per colour pair k
+        const uint32_t e0 = byt[r][0], o0 = byt[r][1], e1 = byt[r][2], o1 = byt[r][3];
+        a.x = add_u16x2(a.x, __builtin_amdgcn_perm(o0, e0, 0x0c040c00u));
+        a.y = add_u16x2(a.y, __builtin_amdgcn_perm(o0, e0, 0x0c050c01u));
+        a.z = add_u16x2(a.z, __builtin_amdgcn_perm(o0, e0, 0x0c060c02u));
+        a.w = add_u16x2(a.w, __builtin_amdgcn_perm(o0, e0, 0x0c070c03u));
+        c.x = add_u16x2(c.x, __builtin_amdgcn_perm(o1, e1, 0x0c040c00u));
+        c.y = add_u16x2(c.y, __builtin_amdgcn_perm(o1, e1, 0x0c050c01u));
+        c.z = add_u16x2(c.z, __builtin_amdgcn_perm(o1, e1, 0x0c060c02u));
+        c.w = add_u16x2(c.w, __builtin_amdgcn_perm(o1, e1, 0x0c070c03u));
+        dst[0] = a;
+        dst[1] = c;
+      }
+      byt[r][0] = byt[r][1] = byt[r][2] = byt[r][3] = 0;
+    }
+    in_byt = 0;
+  }
+  __device__ __forceinline__ void fold_nibbles(const BlitParams& p, int X, int Y0) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const uint32_t a = nib[r][h], e = a & 0x0f0f0f0fu;
+        byt[r][2 * h] += e;
+        byt[r][2 * h + 1] += (a - e) >> 4;
+        nib[r][h] = 0;
+      }
+    in_nib = 0;
+    if (++in_byt == 17) fold_canvas(p, X, Y0);  // 17 x 15 = 255: a byte is full
+  }
+  __device__ __forceinline__ void frame_done(const BlitParams& p, int X, int Y0) {
+    if (++in_nib == 15) fold_nibbles(p, X, Y0);
+  }
+  __device__ __forceinline__ void finish(const BlitParams& p, int X, int Y0) {
+    if (in_nib) fold_nibbles(p, X, Y0);
+    if (in_byt) fold_canvas(p, X, Y0);
+  }
+};
+
+// The frames of one tile, one at a time: a batch of 64 records is tested against the tile's
+// rows by the wave's lanes, the survivors are handed out through readlane (all scalar).
+struct BlitWalk {
+  const uint4* list;
+  uint32_t base, lend, lane;
+  int X0, Y0, R, W, H;
+  uint64_t todo;
+  uint4 rec, rec_next;
+  __device__ __forceinline__ void start(const BlitParams& p, uint32_t group, uint32_t lane_, int X0_, int Y0_, int R_) {
+    list = p.col_list;
+    base = p.col_cnt[group];
+    lend = p.col_cnt[group + 1];
+    lane = lane_;
+    X0 = X0_;
+    Y0 = Y0_;
+    R = R_;
+    W = (int)p.W;
+    H = (int)p.H;
+    todo = 0;
+    rec = rec_next = make_uint4(0, 0, 0, 0);
+    if (base + lane < lend) rec_next = list[base + lane];
+  }
+  __device__ __forceinline__ bool next(uint32_t& f, int& ax, int& ay) {
+    while (todo == 0) {
+      if (base >= lend) return false;
+      rec = rec_next;
+      const bool live = base + lane < lend;
+      base += 64;
+      if (base + lane < lend) rec_next = list[base + lane];
+      const int rx = (int)rec.y, ry = (int)rec.z;
+      todo = __builtin_amdgcn_ballot_w64(live && ry < Y0 + R && ry + H > Y0 && rx < X0 + BL_TW && rx + W > X0);
+    }
+    const int j = (int)__builtin_ctzll(todo);
+    todo &= todo - 1;
+    f = (uint32_t)__builtin_amdgcn_readlane((int)rec.x, j);
+    ax = __builtin_amdgcn_readlane((int)rec.y, j);
+    ay = __builtin_amdgcn_readlane((int)rec.z, j);
+    return true;
+  }
+};
+
+// tile index of this workgroup: workgroups of one XCD (blockIdx % 8) take a contiguous range
+// of tiles, x fastest — neighbours in time share the frames' lines in that XCD's L2
+__device__ __forceinline__ uint32_t blit_tile_of_block() {
+  const uint32_t b = blockIdx.x, nb = gridDim.x, bq = nb >> 3, br = nb & 7u, x = b & 7u;
+  return (x < br ? x * (bq + 1) : br * (bq + 1) + (x - br) * bq) + (b >> 3);
+}
+
+typedef __attribute__((address_space(3))) void* blit_lds_ptr;
+typedef const __attribute__((address_space(1))) void* blit_glb_ptr;
+
+// Frames at least 64 pixels wide.  The memory side is what bounds this kernel: a wave's vector
+// memory instruction costs the CU's address unit 16 cycles whatever its width, so a byte per
+// lane and row (12 M wave-loads per 10 000 frames) is 0.3 ms of address time alone.  Instead
+// ONE 16-byte-per-lane load per frame brings the tile's R rows x 64 bytes (lane j: row j / 4,
+// piece j % 4) straight into LDS (LDS-DMA: no VGPRs, D frames in flight per wave), and a lane
+// picks its column's R bytes out of LDS.  The 64-byte window is clamped into the frame's row,
+// the lanes read it at the matching shift; lanes beside the frame add zero.
+template <int R, int D, bool MASK>
 __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
-  // bins[k][slot]: dword k (bins 2k, 2k+1) of the pixel in `slot`; a thread's pixel j sits in
-  // slot row*128 + j*32 + (tid & 31), so for any k the 32 lanes of a half-wave hit 32
-  // different banks whatever colours they carry (a [pixel][8] layout is a 32-way conflict)
-  __shared__ uint32_t bins[9][BL_TW * BL_TH];  // 32 KB + a ninth row nobody reads: pixels outside a frame or masked out land there
-  __shared__ uint32_t list[256];
-  __shared__ int list_ax[256], list_ay[256];  // canvas origin of the listed frames
-  __shared__ uint32_t nlist;
-  const uint32_t tid = threadIdx.x;
-  const int tx0 = (int)(blockIdx.x % p.tiles_x) * BL_TW, ty0 = (int)(blockIdx.x / p.tiles_x) * BL_TH;
-  const int row = (int)(tid >> 5), xq = (int)(tid & 31u) * 4;  // this thread: 4 pixels of one row
-  const int X = tx0 + xq, Y = ty0 + row;                      // canvas coordinates
-  const uint32_t slot0 = (uint32_t)row * BL_TW + (tid & 31u);
-  // The bins hold only THIS launch's increments (at most 65 535 frames per launch, so no half
-  // of a word can overflow into the other): a pixel is then one fire-and-forget ds_add_u32,
-  // no read-modify-write chain, and the canvas content is added once at the end with its
-  // uint16 wraparound (fgm.hpp:14).
-  const bool in_canvas_row = Y < (int)p.ch;
-#pragma unroll
-  for (int k = 0; k < 8; ++k)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) bins[k][slot0 + (uint32_t)j * 32] = 0;
+  __shared__ __attribute__((aligned(16))) uint8_t ring[4][D][MASK ? 2 : 1][R * 64];
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (uniform: the frame walk runs on the scalar unit)
+  const uint32_t b = blit_tile_of_block();
+  const uint32_t group = b % p.groups_x, tcol = group * 4 + wv;
+  if (tcol >= p.tiles_x) return;  // (no barriers in this kernel)
+  const int Y0 = (int)(b / p.groups_x) * R;
+  const int X0 = (int)(tcol * BL_TW), X = X0 + (int)lane;
   const int W = (int)p.W, H = (int)p.H;
-  const int YW = Y * W;
-  const uint32_t tcol = blockIdx.x % p.tiles_x;
-  const uint32_t lbeg = p.col_cnt[tcol], lend = p.col_cnt[tcol + 1];  // this tile column's frames
-  for (uint32_t base = lbeg; base < lend; base += 256) {
-    __syncthreads();
-    if (tid == 0) nlist = 0;
-    __syncthreads();
-    if (base + tid < lend) {
-      const uint32_t f = p.col_list[base + tid];
-      const int ax = p.pos[2 * f] - p.zx, ay = p.pos[2 * f + 1] - p.zy;  // x overlap is guaranteed by the column list
-      if (ay < ty0 + BL_TH && ay + H > ty0) {
-        const uint32_t at = atomicAdd(&nlist, 1u);
-        list[at] = f;
-        list_ax[at] = ax;
-        list_ay[at] = ay;
+  const uint64_t fbytes = (uint64_t)H * (uint64_t)W;
+  const int lrow = (int)(lane >> 2), lpiece = (int)(lane & 3u) * 16;
+  const uint32_t lane_off = (uint32_t)(lrow * W + lpiece);  // this lane's 16 bytes within the R x 64 window
+
+  BlitCounters<R> cnt;
+  cnt.clear();
+
+  // ---- the frame walk.  64 records at a time: lane i tests record i against the tile and works
+  // out everything a frame needs as a vector operation (once per 64 frames, not per frame):
+  //   w_base  byte offset of the window's first row in the frame plane (all R rows inside the
+  //           frame: "full"), else of the window's column in row 0
+  //   w_info  (shift of the lanes against the window + 64) | full << 8
+  //   w_fy0   first tile row in frame coordinates (used by the rare not-full frames only)
+  // a frame is then popped with three readlanes.
+  const uint32_t lbeg = p.col_cnt[group], lend = p.col_cnt[group + 1];
+  uint32_t base = lbeg;
+  uint64_t todo = 0;
+  uint64_t w_base = 0;
+  uint32_t w_info = 0;
+  int w_fy0 = 0;
+  uint4 rec_next = make_uint4(0, 0, 0, 0);
+  if (base + lane < lend) rec_next = p.col_list[base + lane];
+  auto refill = [&]() -> bool {  // false: the list is exhausted
+    while (todo == 0) {
+      if (base >= lend) return false;
+      const uint4 rec = rec_next;
+      const bool live = base + lane < lend;
+      base += 64;
+      if (base + lane < lend) rec_next = p.col_list[base + lane];
+      const int ax = (int)rec.y, ay = (int)rec.z;
+      const int fy0 = Y0 - ay, sx = X0 - ax;
+      const int sxc = min(max(sx, 0), W - BL_TW);  // the 64-byte window, clamped into the row
+      const bool full = fy0 >= 0 && fy0 + R <= H;
+      w_base = (uint64_t)rec.x * fbytes + (uint64_t)(uint32_t)((full ? fy0 * W : 0) + sxc);
+      w_info = (uint32_t)(sx - sxc + 64) | (full ? 256u : 0u);
+      w_fy0 = fy0;
+      todo = __builtin_amdgcn_ballot_w64(live && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
+    }
+    return true;
+  };
+
+  uint32_t q_info[D];
+  int q_fy0[D];
+  const uint32_t lds_lane = (uint32_t)(uintptr_t)&ring[wv][0][0][0] + lane;  // (LDS byte address: low 32 bits of the pointer)
+  auto issue = [&](int s, int j) {
+    const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)w_info, j);
+    const uint64_t wb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_base, j) |
+                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_base >> 32), j) << 32;
+    q_info[s] = info;
+    if (info & 256u) {  // (uniform) a scalar base and the lane's constant offset
+      if (R == 16 || lane < 4u * R) {
+        __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.frames + wb + lane_off), (blit_lds_ptr)&ring[wv][s][0][0], 16, 0, 0);
+        if (MASK) __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.mask + wb + lane_off), (blit_lds_ptr)&ring[wv][s][MASK ? 1 : 0][0], 16, 0, 0);
+      }
+    } else {
+      const int fy0 = __builtin_amdgcn_readlane(w_fy0, j);
+      q_fy0[s] = fy0;
+      if (R == 16 || lane < 4u * R) {
+        const int row = min(max(fy0 + lrow, 0), H - 1);  // rows outside the frame: a valid address, not counted
+        const uint64_t off = wb + (uint64_t)(uint32_t)(row * W + lpiece);
+        __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.frames + off), (blit_lds_ptr)&ring[wv][s][0][0], 16, 0, 0);
+        if (MASK) __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.mask + off), (blit_lds_ptr)&ring[wv][s][MASK ? 1 : 0][0], 16, 0, 0);
       }
     }
-    __syncthreads();
-    const uint32_t m = nlist;
-    // fetch() only ISSUES the loads of one frame's four pixels (and mask bytes): every use of
-    // the loaded dwords is in apply(), so the loads of a whole trip are in flight together.
-    // A dword that would straddle the frame's left/right edge is loaded from the clamped
-    // position and shifted into place afterwards (sh = -3..3); sh = 8: nothing to add.
-    auto fetch = [&](uint32_t i, uint32_t& raw, uint32_t& mraw, int& sh) {
-      raw = 0;
-      mraw = 0;
-      sh = 8;
-      if (i >= m) return;  // (uniform)
-      // the frame and its canvas origin are the same for the whole workgroup: scalar registers, a
-      // buffer descriptor per frame.  Rows above or below the frame give offsets outside the
-      // descriptor (the hardware returns 0, no branch); they are dropped through sh all the same
-      const uint32_t g = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[i]);
-      const int ax = __builtin_amdgcn_readfirstlane(list_ax[i]), ay = __builtin_amdgcn_readfirstlane(list_ay[i]);
-      const size_t fbase = (size_t)g * (size_t)(H * W);
-      const int fx = X - ax, fy = Y - ay;
-      const int fxc = min(max(fx, 0), W - 4);
-      const uint32_t voff = (uint32_t)(YW - ay * W + fxc);
-      raw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blit_rsrc(p.frames + fbase, (uint32_t)(H * W)), voff, 0, 0);
-      if (p.mask) mraw = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(blit_rsrc(p.mask + fbase, (uint32_t)(H * W)), voff, 0, 0);
-      const bool inside = (uint32_t)fy < (uint32_t)H && (uint32_t)(fx + 3) < (uint32_t)(W + 3);
-      sh = inside ? fx - fxc : 8;
-    };
-    auto place = [](uint32_t w, int sh, uint32_t fill) {  // bytes of the clamped dword -> pixel order, `fill` elsewhere
-      if (sh < 0) return (w << (8 * -sh)) | (fill >> (32 + 8 * sh));
-      if (sh > 0) return (w >> (8 * sh)) | (fill << (32 - 8 * sh));
-      return w;
-    };
-    auto apply = [&](uint32_t raw, uint32_t mraw, int sh) {
-      if (sh == 8) return;
-      uint32_t w = place(raw & 0x0f0f0f0fu, sh, 0x10101010u);  // 0x10 in a byte = "outside the frame"
-      if (p.mask) {
-        const uint32_t mw = place(mraw, sh, 0u);
-        const uint32_t nz = (((mw & 0x7f7f7f7fu) + 0x7f7f7f7fu) | mw) & 0x80808080u;  // bit 7 of every non-zero byte
-        const uint32_t out = nz >> 3;                                                  // 0x10 per masked pixel
-        w = (w & ~(out - (out >> 4))) | out;                                           // masked pixel -> "outside"
+  };
+  auto count = [&](int s) {
+    const uint32_t info = q_info[s];
+    const int d = (int)(info & 255u) - 64;
+    // the window lies inside the frame's row, so a lane is inside the frame iff it is inside the
+    // window; the others shift a zero (and read some other byte of LDS, or none)
+    const uint32_t t = lane + (uint32_t)d;
+    const uint32_t one = t < (uint32_t)BL_TW ? 1u : 0u;
+    typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
+    lds_bytes px = (lds_bytes)(uintptr_t)(lds_lane + (uint32_t)d + (uint32_t)(s * (MASK ? 2 : 1) * R * 64));
+    uint32_t v[R], m[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      v[r] = px[r * 64];
+      if (MASK) m[r] = px[R * 64 + r * 64];
+    }
+    if (info & 256u) {
+#pragma unroll
+      for (int r = 0; r < R; ++r) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
+    } else {
+      const int fy0 = q_fy0[s];
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if ((uint32_t)(fy0 + r) < (uint32_t)H) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
+    }
+    cnt.frame_done(p, X, Y0);
+  };
+
+  // D frames in the pipe: a slot's frame is counted D - 1 issues after its load went out.  The
+  // compiler does not count LDS-DMA: loads land in order, so all but the D - 1 youngest (each
+  // frame is one load, two with a mask) have landed after vmcnt(that many); draining: vmcnt(0)
+  bool have[D];
+#pragma unroll
+  for (int s = 0; s < D; ++s) have[s] = false;
+  bool more = true;
+  while (more) {
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      if (!more) break;
+      if (have[s]) {
+        if (MASK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
+        count(s);
       }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        // branch-free, five VALU ops per pixel: colour c adds 1 to half c & 1 of dword c >> 1;
-        // "outside" (16) adds to the ninth row (a compare-and-select to add 0 instead: ten)
-        const uint32_t v = (w >> (8 * j)) & 0x1fu;
-        const uint32_t inc = 1u + (v & 1u) * 0xffffu;
-        __hip_atomic_fetch_add(&bins[v >> 1][slot0 + (uint32_t)j * 32], inc, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    };
-    // eight frames per trip, the next trip's loads issued before this trip's updates
-    uint32_t cur[8], curm[8], nxt[8], nxtm[8];
-    int csh[8], nsh[8];
-#pragma unroll
-    for (int k = 0; k < 8; ++k) fetch((uint32_t)k, cur[k], curm[k], csh[k]);
-    for (uint32_t i = 0; i < m; i += 8) {
-#pragma unroll
-      for (int k = 0; k < 8; ++k) fetch(i + 8 + (uint32_t)k, nxt[k], nxtm[k], nsh[k]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) apply(cur[k], curm[k], csh[k]);
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        cur[k] = nxt[k];
-        curm[k] = nxtm[k];
-        csh[k] = nsh[k];
+      more = have[s] = refill();
+      if (more) {
+        const int j = (int)__builtin_ctzll(todo);
+        todo &= todo - 1;
+        issue(s, j);
       }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    if (in_canvas_row && X + j < (int)p.cw) {
-      const uint32_t sl = slot0 + (uint32_t)j * 32;
-      uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)(X + j)) * 8);
-      const uint4 a = dst[0], b = dst[1];
-      dst[0] = make_uint4(add_u16x2(a.x, bins[0][sl]), add_u16x2(a.y, bins[1][sl]), add_u16x2(a.z, bins[2][sl]),
-                          add_u16x2(a.w, bins[3][sl]));
-      dst[1] = make_uint4(add_u16x2(b.x, bins[4][sl]), add_u16x2(b.y, bins[5][sl]), add_u16x2(b.z, bins[6][sl]),
-                          add_u16x2(b.w, bins[7][sl]));
+  for (int s = 0; s < D; ++s)
+    if (have[s]) count(s);
+  cnt.finish(p, X, Y0);
+}
+
+// Frames narrower than 64 pixels: a byte per lane and row, loaded straight into registers.
+template <int R, bool MASK>
+__global__ __launch_bounds__(256) void fgm_blit_narrow(BlitParams p) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const uint32_t b = blit_tile_of_block();
+  const uint32_t group = b % p.groups_x, tcol = group * 4 + wv;
+  if (tcol >= p.tiles_x) return;
+  const int Y0 = (int)(b / p.groups_x) * R;
+  const int X = (int)(tcol * BL_TW + lane);
+  const int W = (int)p.W, H = (int)p.H;
+  const uint32_t fbytes = (uint32_t)(H * W);
+  BlitCounters<R> cnt;
+  cnt.clear();
+  BlitWalk walk;
+  walk.start(p, group, lane, (int)(tcol * BL_TW), Y0, R);
+  struct Pend {
+    uint32_t v[R], m[R];
+    uint32_t one;
+    int fy0;
+  };
+  auto issue = [&](Pend& q, uint32_t f, int ax, int ay) {
+    const int xoff = X - ax;
+    const bool in = (uint32_t)xoff < (uint32_t)W;
+    q.one = in ? 1u : 0u;
+    q.fy0 = Y0 - ay;
+    const uint32_t voff = in ? (uint32_t)xoff : 0u;  // lanes beside the frame read its column 0 and add zero
+    const size_t fbase = (size_t)f * fbytes;
+    const __amdgpu_buffer_rsrc_t rs = blit_rsrc(p.frames + fbase, fbytes);
+    const __amdgpu_buffer_rsrc_t rm = blit_rsrc((MASK ? p.mask : p.frames) + fbase, fbytes);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int so = min(max(q.fy0 + r, 0), H - 1) * W;  // rows outside the frame: a valid address, not counted
+      q.v[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rs, (int)voff, so, 0);
+      if (MASK) q.m[r] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)voff, so, 0);
+    }
+  };
+  auto count = [&](const Pend& q) {
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+      if ((uint32_t)(q.fy0 + r) < (uint32_t)H) cnt.add(r, q.v[r], MASK ? (q.m[r] == 0 ? q.one : 0u) : q.one);
+    cnt.frame_done(p, X, Y0);
+  };
+  Pend q[2];
+  bool have[2] = {false, false};
+  bool more = true;
+  while (more) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+      if (!more) break;
+      if (have[s]) count(q[s]);
+      uint32_t f;
+      int ax, ay;
+      more = have[s] = walk.next(f, ax, ay);
+      if (more) issue(q[s], f, ax, ay);
     }
   }
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+    if (have[s]) count(q[s]);
+  cnt.finish(p, X, Y0);
 }
 
 // ---- fgm::fragment::blit(pos, fragment&&) canvas part (fgm.hpp:99-113) ------------------------

@@ -294,16 +294,18 @@ class Aligner:
         every rank's sub-canvas at (zero - global_zero) with uint16 wraparound gives the
         reference canvas (fgm.hpp:99-113); with one rank the sub-box is the whole box."""
         t = self.torch
-        pos_h = pos.cpu().numpy()
-        frag_h = frag.cpu().numpy()
-        local_frags = np.unique(frag_h[lo:hi])
+        # positions and fragment ids in ONE copy to the host (one wait instead of two)
+        both = t.cat([pos, frag.to(t.int32)[:, None]], dim=1).cpu().numpy()
+        pos_h, frag_h = both[:, :2], both[:, 2]
+        one = bool(frag_h.min() == frag_h.max())  # a single fragment (the common case): no masks
+        local_frags = [frag_h[lo]] if one else np.unique(frag_h[lo:hi])
         canvases = {}
         pos_l = pos[lo:hi].contiguous()
         frag_l = frag[lo:hi].contiguous()
         for fid in local_frags:
-            sel = frag_h == fid
-            gw, gh, gzx, gzy = self.ctx.fgm_extent(pos_h[sel])
-            loc = pos_h[lo:hi][frag_h[lo:hi] == fid]
+            sel = slice(None) if one else frag_h == fid
+            gw, gh, gzx, gzy = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[sel]))
+            loc = pos_h[lo:hi] if one else pos_h[lo:hi][frag_h[lo:hi] == fid]
             # step-aligned sub-box (in steps from the global zero) covering the local frames
             x0 = (int(loc[:, 0].min()) - gzx) // self.W * self.W
             y0 = (int(loc[:, 1].min()) - gzy) // self.H * self.H

@@ -92,6 +92,69 @@ def test_blit_uint16_wraparound(gpu):
     ctx.close()
 
 
+def test_blit_wide_path_wraparound_and_folds(gpu):
+    # frames >= 64 pixels wide take the LDS-DMA kernel: 4-bit counters folded into bytes every 15
+    # frames, bytes into the canvas every 255 — far more than either on one spot, past 65 535 too
+    import torch
+
+    W, H, n = 64, 8, 65536 + 300
+    rng = np.random.default_rng(3)
+    base = rng.integers(0, 16, size=(7, H, W), dtype=np.uint8)
+    which = rng.integers(0, 7, size=n)
+    ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+    d = torch.from_numpy(base).cuda()[torch.from_numpy(which).cuda()].contiguous()
+    pos = torch.zeros((n, 2), dtype=torch.int32, device="cuda")
+    canvas = torch.full((H, W, 16), 7, dtype=torch.int16, device="cuda")  # not empty: the launch ADDS
+    ctx.fgm_blit(d, pos, canvas, (0, 0))
+    exp = np.full((H, W, 16), 7, np.int64)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for k in range(7):
+        exp[yy, xx, base[k]] += int((which == k).sum())
+    assert np.array_equal(canvas.cpu().numpy().view(np.uint16), (exp % 65536).astype(np.uint16))
+    ctx.close()
+
+
+def test_blit_jitter_many_hits_partial_rows(gpu):
+    # hundreds of frames jittering around one place: every canvas dot is hit > 255 times, most
+    # frames cover a tile's rows and columns only partly (the clamped window, the row checks)
+    import torch
+
+    rng = np.random.default_rng(12)
+    for W, H, n in ((96, 40, 700), (200, 30, 400), (64, 9, 300)):
+        frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
+        pos = rng.integers(-21, 22, size=(n, 2)).astype(np.int32)
+        pos[0] = 0
+        ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+        cw, ch, zx, zy = ctx.fgm_extent(pos)
+        ocan = np.zeros((ch, cw, 16), np.uint16)
+        for i in range(n):
+            O.orc_fgm_blit(ocan, (zx, zy), frames[i], pos[i])
+        canvas = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+        ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy))
+        assert np.array_equal(canvas.cpu().numpy().view(np.uint16), ocan), (W, H)
+        ctx.close()
+
+
+def test_blit_narrow_frames(gpu):
+    # frames under 64 pixels wide take the byte-per-lane kernel
+    import torch
+
+    rng = np.random.default_rng(13)
+    for W, H, n in ((16, 8, 500), (60, 33, 300), (63, 9, 100)):
+        frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
+        pos = np.cumsum(rng.integers(-3, 4, size=(n, 2)), axis=0).astype(np.int32)
+        pos[0] = 0
+        ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+        cw, ch, zx, zy = ctx.fgm_extent(pos)
+        ocan = np.zeros((ch, cw, 16), np.uint16)
+        for i in range(n):
+            O.orc_fgm_blit(ocan, (zx, zy), frames[i], pos[i])
+        canvas = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+        ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy))
+        assert np.array_equal(canvas.cpu().numpy().view(np.uint16), ocan), (W, H)
+        ctx.close()
+
+
 def test_blit_odd_width(gpu):
     import torch
 
