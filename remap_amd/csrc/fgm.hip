@@ -411,10 +411,9 @@ __device__ __forceinline__ uint32_t blit_tile_of_block() {
 typedef __attribute__((address_space(3))) void* blit_lds_ptr;
 typedef const __attribute__((address_space(1))) void* blit_glb_ptr;
 
-// Frames at least 64 pixels wide.  The memory side is what bounds this kernel: a wave's vector
-// memory instruction costs the CU's address unit 16 cycles whatever its width, so a byte per
-// lane and row (12 M wave-loads per 10 000 frames) is 0.3 ms of address time alone.  Instead
-// ONE 16-byte-per-lane load per frame brings the tile's R rows x 64 bytes (lane j: row j / 4,
+// Frames at least 64 pixels wide.  The memory side is what bounds this kernel (the 128-byte lines
+// its 64-byte windows touch), so the load path is kept as light as it gets: ONE
+// 16-byte-per-lane load per frame brings the tile's R rows x 64 bytes (lane j: row j / 4,
 // piece j % 4) straight into LDS (LDS-DMA: no VGPRs, D frames in flight per wave), and a lane
 // picks its column's R bytes out of LDS.  The 64-byte window is clamped into the frame's row,
 // the lanes read it at the matching shift; lanes beside the frame add zero.
