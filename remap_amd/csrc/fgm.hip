@@ -195,13 +195,14 @@ struct BlitParams {
   // workgroup walk the same list in the same order, each skipping what misses its own tile
   uint32_t* col_cnt;  // groups_x + 1: counts, then exclusive offsets (in place)
   uint32_t* col_cur;  // groups_x fill cursors
-  uint4* col_list;    // (frame, canvas x, canvas y, -) records, <= n * (W / 256 + 2)
+  uint4* col_list;    // (frame, canvas x, canvas y, -) records, <= n * (W / 256 + 2); nullptr: a short batch, not binned
 };
 
 constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
 // rows of a wave's tile and frames in its pipe (measured: 8 x 2..8 and 4 x 4..8 within 3 %, 16 rows slower);
 // the byte-per-lane kernel for narrow frames holds two frames of 4 rows in registers
 constexpr int BL_ROWS = 8, BL_DEPTH = 4, BL_ROWS_NARROW = 4;
+constexpr uint32_t BL_DIRECT_MAX = 1024;  // batches up to this many frames skip the binning passes
 
 // A frame overlaps at most W/256 + 2 groups; three tiny passes bin the batch's frames by
 // group so that a tile walks ~(W + 256) / (mean step) frames instead of all n.
@@ -360,18 +361,32 @@ struct BlitCounters {
   }
 };
 
+// Record i of a tile's frame list: (frame, canvas x, canvas y, live).  With binned lists it is
+// read from the group's list; a short batch (col_list == nullptr) is not binned at all — every
+// tile tests every frame of the batch, the record comes straight from the position arrays.
+__device__ __forceinline__ uint4 blit_record(const BlitParams& p, uint32_t i, uint32_t lend) {
+  if (i >= lend) return make_uint4(0, 0, 0, 0);
+  if (p.col_list) {
+    uint4 r = p.col_list[i];
+    r.w = 1u;
+    return r;
+  }
+  const bool live = !(p.frag_id && p.frag_id[i] != p.fragment);
+  return make_uint4(i, (uint32_t)(p.pos[2 * i] - p.zx), (uint32_t)(p.pos[2 * i + 1] - p.zy), live ? 1u : 0u);
+}
+
 // The frames of one tile, one at a time: a batch of 64 records is tested against the tile's
 // rows by the wave's lanes, the survivors are handed out through readlane (all scalar).
 struct BlitWalk {
-  const uint4* list;
+  const BlitParams* pp;
   uint32_t base, lend, lane;
   int X0, Y0, R, W, H;
   uint64_t todo;
   uint4 rec, rec_next;
   __device__ __forceinline__ void start(const BlitParams& p, uint32_t group, uint32_t lane_, int X0_, int Y0_, int R_) {
-    list = p.col_list;
-    base = p.col_cnt[group];
-    lend = p.col_cnt[group + 1];
+    pp = &p;
+    base = p.col_list ? p.col_cnt[group] : 0u;
+    lend = p.col_list ? p.col_cnt[group + 1] : p.n;
     lane = lane_;
     X0 = X0_;
     Y0 = Y0_;
@@ -379,16 +394,16 @@ struct BlitWalk {
     W = (int)p.W;
     H = (int)p.H;
     todo = 0;
-    rec = rec_next = make_uint4(0, 0, 0, 0);
-    if (base + lane < lend) rec_next = list[base + lane];
+    rec = make_uint4(0, 0, 0, 0);
+    rec_next = blit_record(p, base + lane, lend);
   }
   __device__ __forceinline__ bool next(uint32_t& f, int& ax, int& ay) {
     while (todo == 0) {
       if (base >= lend) return false;
       rec = rec_next;
-      const bool live = base + lane < lend;
+      const bool live = rec.w != 0;
       base += 64;
-      if (base + lane < lend) rec_next = list[base + lane];
+      rec_next = blit_record(*pp, base + lane, lend);
       const int rx = (int)rec.y, ry = (int)rec.z;
       todo = __builtin_amdgcn_ballot_w64(live && ry < Y0 + R && ry + H > Y0 && rx < X0 + BL_TW && rx + W > X0);
     }
@@ -442,21 +457,20 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   //   w_info  (shift of the lanes against the window + 64) | full << 8
   //   w_fy0   first tile row in frame coordinates (used by the rare not-full frames only)
   // a frame is then popped with three readlanes.
-  const uint32_t lbeg = p.col_cnt[group], lend = p.col_cnt[group + 1];
-  uint32_t base = lbeg;
+  const uint32_t lend = p.col_list ? p.col_cnt[group + 1] : p.n;
+  uint32_t base = p.col_list ? p.col_cnt[group] : 0u;
   uint64_t todo = 0;
   uint64_t w_base = 0;
   uint32_t w_info = 0;
   int w_fy0 = 0;
-  uint4 rec_next = make_uint4(0, 0, 0, 0);
-  if (base + lane < lend) rec_next = p.col_list[base + lane];
+  uint4 rec_next = blit_record(p, base + lane, lend);
   auto refill = [&]() -> bool {  // false: the list is exhausted
     while (todo == 0) {
       if (base >= lend) return false;
       const uint4 rec = rec_next;
-      const bool live = base + lane < lend;
+      const bool live = rec.w != 0;
       base += 64;
-      if (base + lane < lend) rec_next = p.col_list[base + lane];
+      rec_next = blit_record(p, base + lane, lend);
       const int ax = (int)rec.y, ay = (int)rec.z;
       const int fy0 = Y0 - ay, sx = X0 - ax;
       const int sxc = min(max(sx, 0), W - BL_TW);  // the 64-byte window, clamped into the row

@@ -286,6 +286,26 @@ class Aligner:
         allr = gather_block_rows(rows, counts, self.dist, self.group)
         out["pos_all"], out["frag_all"] = allr[:, :2].contiguous(), allr[:, 2].contiguous()
 
+    def _blit_one(self, frames, pos, frag, fid, loc, ext, fa, fb, pa, pb):
+        """One fragment's sub-canvas: frames[fa:fb] at pos[pa:pb] (filtered by `frag` == fid when
+        given); `loc` = the host copy of those positions, `ext` = the fragment's global box."""
+        t = self.torch
+        gw, gh, gzx, gzy = ext
+        # step-aligned sub-box (in steps from the global zero) covering the local frames
+        x0 = (int(loc[:, 0].min()) - gzx) // self.W * self.W
+        y0 = (int(loc[:, 1].min()) - gzy) // self.H * self.H
+        x1 = -((-(int(loc[:, 0].max()) + self.W - gzx)) // self.W) * self.W
+        y1 = -((-(int(loc[:, 1].max()) + self.H - gzy)) // self.H) * self.H
+        cw, ch, zx, zy = x1 - x0, y1 - y0, gzx + x0, gzy + y0
+        key = ("canvas", int(fid))
+        c = self._bufs.get(key)
+        if c is None or tuple(c.shape) != (ch, cw, 16):
+            c = t.empty((ch, cw, 16), dtype=t.int16, device=self.ctx.device)
+            self._bufs[key] = c
+        c.zero_()
+        self.ctx.fgm_blit(frames[fa:fb], pos[pa:pb], c, (zx, zy), frag_id=frag, fragment=int(fid))
+        return (c, (zx, zy), (gw, gh, (gzx, gzy)))
+
     def blit(self, frames, pos, frag, lo, hi):
         """fgm::fragment::blit of this rank's frames.  For every fragment with frames on this
         rank the GLOBAL canvas box (zero, dims) follows from all positions of the fragment
@@ -297,29 +317,30 @@ class Aligner:
         # positions and fragment ids in ONE copy to the host (one wait instead of two)
         both = t.cat([pos, frag.to(t.int32)[:, None]], dim=1).cpu().numpy()
         pos_h, frag_h = both[:, :2], both[:, 2]
-        one = bool(frag_h.min() == frag_h.max())  # a single fragment (the common case): no masks
-        local_frags = [frag_h[lo]] if one else np.unique(frag_h[lo:hi])
         canvases = {}
-        pos_l = pos[lo:hi].contiguous()
-        frag_l = frag[lo:hi].contiguous()
-        for fid in local_frags:
-            sel = slice(None) if one else frag_h == fid
-            gw, gh, gzx, gzy = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[sel]))
-            loc = pos_h[lo:hi] if one else pos_h[lo:hi][frag_h[lo:hi] == fid]
-            # step-aligned sub-box (in steps from the global zero) covering the local frames
-            x0 = (int(loc[:, 0].min()) - gzx) // self.W * self.W
-            y0 = (int(loc[:, 1].min()) - gzy) // self.H * self.H
-            x1 = -((-(int(loc[:, 0].max()) + self.W - gzx)) // self.W) * self.W
-            y1 = -((-(int(loc[:, 1].max()) + self.H - gzy)) // self.H) * self.H
-            cw, ch, zx, zy = x1 - x0, y1 - y0, gzx + x0, gzy + y0
-            key = ("canvas", int(fid))
-            c = self._bufs.get(key)
-            if c is None or tuple(c.shape) != (ch, cw, 16):
-                c = t.empty((ch, cw, 16), dtype=t.int16, device=self.ctx.device)
-                self._bufs[key] = c
-            c.zero_()
-            self.ctx.fgm_blit(frames, pos_l, c, (zx, zy), frag_id=frag_l, fragment=int(fid))
-            canvases[int(fid)] = (c, (zx, zy), (gw, gh, (gzx, gzy)))
+        # a fragment's frames are one run of the stream (frc.hpp:97-115: ids count the cuts), so a
+        # fragment is a slice of the batch: no masks, no per-frame fragment test in the kernel
+        cuts = np.flatnonzero(frag_h[1:] != frag_h[:-1]) + 1
+        starts = np.concatenate([[0], cuts])
+        ends = np.concatenate([cuts, [len(frag_h)]])
+        runs_ok = len(np.unique(frag_h[starts])) == len(starts)
+        for a, b in zip(starts, ends):
+            if not runs_ok:
+                break
+            la, lb = max(int(a), lo), min(int(b), hi)
+            if la >= lb:
+                continue
+            fid = int(frag_h[a])
+            gw, gh, gzx, gzy = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[a:b]))
+            canvases[fid] = self._blit_one(frames, pos, None, fid, pos_h[la:lb], (gw, gh, gzx, gzy), la - lo, lb - lo, la, lb)
+        if not runs_ok:  # (ids out of order: select by mask)
+            pos_l = pos[lo:hi].contiguous()
+            frag_l = frag[lo:hi].contiguous()
+            for fid in np.unique(frag_h[lo:hi]):
+                sel = frag_h == fid
+                ext = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[sel]))
+                loc = pos_h[lo:hi][frag_h[lo:hi] == fid]
+                canvases[int(fid)] = self._blit_one(frames, pos_l, frag_l, int(fid), loc, ext, 0, hi - lo, 0, hi - lo)
         return canvases
 
     def fragments(self, frames, out):

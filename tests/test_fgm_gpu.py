@@ -120,7 +120,7 @@ def test_blit_jitter_many_hits_partial_rows(gpu):
     import torch
 
     rng = np.random.default_rng(12)
-    for W, H, n in ((96, 40, 700), (200, 30, 400), (64, 9, 300)):
+    for W, H, n in ((96, 40, 700), (200, 30, 400), (64, 9, 300), (96, 40, 1300)):  # the last one is binned (> 1024 frames)
         frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
         pos = rng.integers(-21, 22, size=(n, 2)).astype(np.int32)
         pos[0] = 0
@@ -140,7 +140,7 @@ def test_blit_narrow_frames(gpu):
     import torch
 
     rng = np.random.default_rng(13)
-    for W, H, n in ((16, 8, 500), (60, 33, 300), (63, 9, 100)):
+    for W, H, n in ((16, 8, 500), (60, 33, 300), (63, 9, 100), (16, 8, 1200)):
         frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
         pos = np.cumsum(rng.integers(-3, 4, size=(n, 2)), axis=0).astype(np.int32)
         pos[0] = 0
