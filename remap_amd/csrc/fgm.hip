@@ -454,8 +454,8 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   // out everything a frame needs as a vector operation (once per 64 frames, not per frame):
   //   w_base  byte offset of the window's first row in the frame plane (all R rows inside the
   //           frame: "full"), else of the window's column in row 0
-  //   w_info  (shift of the lanes against the window + 64) | full << 8
-  //   w_fy0   first tile row in frame coordinates (used by the rare not-full frames only)
+  //   w_info  (shift of the lanes against the window + 64) | full << 8 | rows inside the frame << 16
+  //   w_fy0   first tile row in frame coordinates (used by the loads of the rare not-full frames)
   // a frame is then popped with three readlanes.
   const uint32_t lend = p.col_list ? p.col_cnt[group + 1] : p.n;
   uint32_t base = p.col_list ? p.col_cnt[group] : 0u;
@@ -476,7 +476,11 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       const int sxc = min(max(sx, 0), W - BL_TW);  // the 64-byte window, clamped into the row
       const bool full = fy0 >= 0 && fy0 + R <= H;
       w_base = (uint64_t)rec.x * fbytes + (uint64_t)(uint32_t)((full ? fy0 * W : 0) + sxc);
-      w_info = (uint32_t)(sx - sxc + 64) | (full ? 256u : 0u);
+      uint32_t rows = 0;  // the tile's rows that lie inside the frame
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if ((uint32_t)(fy0 + r) < (uint32_t)H) rows |= 1u << r;
+      w_info = (uint32_t)(sx - sxc + 64) | (full ? 256u : 0u) | rows << 16;
       w_fy0 = fy0;
       todo = __builtin_amdgcn_ballot_w64(live && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
     }
@@ -484,7 +488,6 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   };
 
   uint32_t q_info[D];
-  int q_fy0[D];
   const uint32_t lds_lane = (uint32_t)(uintptr_t)&ring[wv][0][0][0] + lane;  // (LDS byte address: low 32 bits of the pointer)
   auto issue = [&](int s, int j) {
     const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)w_info, j);
@@ -498,7 +501,6 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       }
     } else {
       const int fy0 = __builtin_amdgcn_readlane(w_fy0, j);
-      q_fy0[s] = fy0;
       if (R == 16 || lane < 4u * R) {
         const int row = min(max(fy0 + lrow, 0), H - 1);  // rows outside the frame: a valid address, not counted
         const uint64_t off = wb + (uint64_t)(uint32_t)(row * W + lpiece);
@@ -522,15 +524,12 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       v[r] = px[r * 64];
       if (MASK) m[r] = px[R * 64 + r * 64];
     }
-    if (info & 256u) {
+    // ONE counting sequence with a (uniform, nearly always taken) test per row: a separate
+    // sequence for frames that cover all rows made the compiler copy the 16 counters back
+    // where the two met (16 v_mov per frame, a quarter of the kernel's VALU instructions)
 #pragma unroll
-      for (int r = 0; r < R; ++r) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
-    } else {
-      const int fy0 = q_fy0[s];
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if ((uint32_t)(fy0 + r) < (uint32_t)H) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
-    }
+    for (int r = 0; r < R; ++r)
+      if (__builtin_expect((info >> (16 + r) & 1u) != 0, 1)) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
     cnt.frame_done(p, X, Y0);
   };
 
