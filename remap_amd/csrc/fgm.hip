@@ -454,113 +454,116 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   // out everything a frame needs as a vector operation (once per 64 frames, not per frame):
   //   w_base  byte offset of the window's first row in the frame plane (all R rows inside the
   //           frame: "full"), else of the window's column in row 0
-  //   w_info  (shift of the lanes against the window + 64) | full << 8 | rows inside the frame << 16
-  //   w_fy0   first tile row in frame coordinates (used by the loads of the rare not-full frames)
+  //   w_info  (shift of the lanes against the window + 64) | rows inside the frame << 16
+  //   w_fy0   first tile row in frame coordinates (not-full frames only)
   // a frame is then popped with three readlanes.
-  const uint32_t lend = p.col_list ? p.col_cnt[group + 1] : p.n;
-  uint32_t base = p.col_list ? p.col_cnt[group] : 0u;
-  uint64_t todo = 0;
-  uint64_t w_base = 0;
-  uint32_t w_info = 0;
-  int w_fy0 = 0;
-  uint4 rec_next = blit_record(p, base + lane, lend);
-  auto refill = [&]() -> bool {  // false: the list is exhausted
-    while (todo == 0) {
-      if (base >= lend) return false;
-      const uint4 rec = rec_next;
-      const bool live = rec.w != 0;
-      base += 64;
-      rec_next = blit_record(p, base + lane, lend);
-      const int ax = (int)rec.y, ay = (int)rec.z;
-      const int fy0 = Y0 - ay, sx = X0 - ax;
-      const int sxc = min(max(sx, 0), W - BL_TW);  // the 64-byte window, clamped into the row
-      const bool full = fy0 >= 0 && fy0 + R <= H;
-      w_base = (uint64_t)rec.x * fbytes + (uint64_t)(uint32_t)((full ? fy0 * W : 0) + sxc);
-      uint32_t rows = 0;  // the tile's rows that lie inside the frame
-#pragma unroll
-      for (int r = 0; r < R; ++r)
-        if ((uint32_t)(fy0 + r) < (uint32_t)H) rows |= 1u << r;
-      w_info = (uint32_t)(sx - sxc + 64) | (full ? 256u : 0u) | rows << 16;
-      w_fy0 = fy0;
-      todo = __builtin_amdgcn_ballot_w64(live && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
-    }
-    return true;
-  };
-
-  uint32_t q_info[D];
+  // The list is walked TWICE: first the frames that cover all R rows of the tile (nearly all),
+  // counted by a straight sequence of 4 R instructions, then the others with a test per row.
+  // (One loop with both sequences made the compiler copy the 16 counters back where they met —
+  // a quarter of the kernel's VALU instructions; one loop with a test per row for every frame
+  // spends as many scalar instructions and branches.  The kernel is bound by the instructions
+  // it issues, of all kinds: DESIGN.md 4.4.)
   const uint32_t lds_lane = (uint32_t)(uintptr_t)&ring[wv][0][0][0] + lane;  // (LDS byte address: low 32 bits of the pointer)
-  auto issue = [&](int s, int j) {
-    const uint32_t info = (uint32_t)__builtin_amdgcn_readlane((int)w_info, j);
-    const uint64_t wb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_base, j) |
-                        (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_base >> 32), j) << 32;
-    q_info[s] = info;
-    if (info & 256u) {  // (uniform) a scalar base and the lane's constant offset
-      if (R == 16 || lane < 4u * R) {
-        __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.frames + wb + lane_off), (blit_lds_ptr)&ring[wv][s][0][0], 16, 0, 0);
-        if (MASK) __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.mask + wb + lane_off), (blit_lds_ptr)&ring[wv][s][MASK ? 1 : 0][0], 16, 0, 0);
+  auto pass = [&](auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const uint32_t lend = p.col_list ? p.col_cnt[group + 1] : p.n;
+    uint32_t base = p.col_list ? p.col_cnt[group] : 0u;
+    uint64_t todo = 0;
+    uint64_t w_base = 0;
+    uint32_t w_info = 0;
+    int w_fy0 = 0;
+    uint4 rec_next = blit_record(p, base + lane, lend);
+    auto refill = [&]() -> bool {  // false: the list is exhausted
+      while (todo == 0) {
+        if (base >= lend) return false;
+        const uint4 rec = rec_next;
+        const bool live = rec.w != 0;
+        base += 64;
+        rec_next = blit_record(p, base + lane, lend);
+        const int ax = (int)rec.y, ay = (int)rec.z;
+        const int fy0 = Y0 - ay, sx = X0 - ax;
+        const int sxc = min(max(sx, 0), W - BL_TW);  // the 64-byte window, clamped into the row
+        const bool full = fy0 >= 0 && fy0 + R <= H;
+        uint32_t rows = 0;  // the tile's rows that lie inside the frame
+        if (!FULL) {
+#pragma unroll
+          for (int r = 0; r < R; ++r)
+            if ((uint32_t)(fy0 + r) < (uint32_t)H) rows |= 1u << r;
+        }
+        w_base = (uint64_t)rec.x * fbytes + (uint64_t)(uint32_t)((FULL ? fy0 * W : 0) + sxc);
+        w_info = (uint32_t)(sx - sxc + 64) | rows << 16;
+        w_fy0 = fy0;
+        todo = __builtin_amdgcn_ballot_w64(live && full == FULL && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
       }
-    } else {
-      const int fy0 = __builtin_amdgcn_readlane(w_fy0, j);
-      if (R == 16 || lane < 4u * R) {
+      return true;
+    };
+    uint32_t q_info[D];
+    auto issue = [&](int s, int j) {
+      q_info[s] = (uint32_t)__builtin_amdgcn_readlane((int)w_info, j);
+      const uint64_t wb = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w_base, j) |
+                          (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w_base >> 32), j) << 32;
+      uint64_t off = wb + lane_off;  // (full: a scalar base and the lane's constant offset)
+      if (!FULL) {
+        const int fy0 = __builtin_amdgcn_readlane(w_fy0, j);
         const int row = min(max(fy0 + lrow, 0), H - 1);  // rows outside the frame: a valid address, not counted
-        const uint64_t off = wb + (uint64_t)(uint32_t)(row * W + lpiece);
+        off = wb + (uint64_t)(uint32_t)(row * W + lpiece);
+      }
+      if (R == 16 || lane < 4u * R) {
         __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.frames + off), (blit_lds_ptr)&ring[wv][s][0][0], 16, 0, 0);
         if (MASK) __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.mask + off), (blit_lds_ptr)&ring[wv][s][MASK ? 1 : 0][0], 16, 0, 0);
       }
-    }
-  };
-  auto count = [&](int s) {
-    const uint32_t info = q_info[s];
-    const int d = (int)(info & 255u) - 64;
-    // the window lies inside the frame's row, so a lane is inside the frame iff it is inside the
-    // window; the others shift a zero (and read some other byte of LDS, or none)
-    const uint32_t t = lane + (uint32_t)d;
-    const uint32_t one = t < (uint32_t)BL_TW ? 1u : 0u;
-    typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
-    lds_bytes px = (lds_bytes)(uintptr_t)(lds_lane + (uint32_t)d + (uint32_t)(s * (MASK ? 2 : 1) * R * 64));
-    uint32_t v[R], m[R];
+    };
+    auto count = [&](int s) {
+      const uint32_t info = q_info[s];
+      const int d = (int)(info & 255u) - 64;
+      // the window lies inside the frame's row, so a lane is inside the frame iff it is inside the
+      // window; the others shift a zero (and read some other byte of LDS, or none)
+      const uint32_t t = lane + (uint32_t)d;
+      const uint32_t one = t < (uint32_t)BL_TW ? 1u : 0u;
+      typedef __attribute__((address_space(3))) const uint8_t* lds_bytes;
+      lds_bytes px = (lds_bytes)(uintptr_t)(lds_lane + (uint32_t)d + (uint32_t)(s * (MASK ? 2 : 1) * R * 64));
+      uint32_t v[R], m[R];
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      v[r] = px[r * 64];
-      if (MASK) m[r] = px[R * 64 + r * 64];
-    }
-    // ONE counting sequence with a (uniform, nearly always taken) test per row: a separate
-    // sequence for frames that cover all rows made the compiler copy the 16 counters back
-    // where the two met (16 v_mov per frame, a quarter of the kernel's VALU instructions)
-#pragma unroll
-    for (int r = 0; r < R; ++r)
-      if (__builtin_expect((info >> (16 + r) & 1u) != 0, 1)) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
-    cnt.frame_done(p, X, Y0);
-  };
-
-  // D frames in the pipe: a slot's frame is counted D - 1 issues after its load went out.  The
-  // compiler does not count LDS-DMA: loads land in order, so all but the D - 1 youngest (each
-  // frame is one load, two with a mask) have landed after vmcnt(that many); draining: vmcnt(0)
-  bool have[D];
-#pragma unroll
-  for (int s = 0; s < D; ++s) have[s] = false;
-  bool more = true;
-  while (more) {
-#pragma unroll
-    for (int s = 0; s < D; ++s) {
-      if (!more) break;
-      if (have[s]) {
-        if (MASK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
-        count(s);
+      for (int r = 0; r < R; ++r) {
+        v[r] = px[r * 64];
+        if (MASK) m[r] = px[R * 64 + r * 64];
       }
-      more = have[s] = refill();
-      if (more) {
-        const int j = (int)__builtin_ctzll(todo);
-        todo &= todo - 1;
-        issue(s, j);
+#pragma unroll
+      for (int r = 0; r < R; ++r)
+        if (FULL || (info >> (16 + r) & 1u)) cnt.add(r, v[r], MASK ? (m[r] == 0 ? one : 0u) : one);
+      cnt.frame_done(p, X, Y0);
+    };
+    // D frames in the pipe: a slot's frame is counted D - 1 issues after its load went out.  The
+    // compiler does not count LDS-DMA: loads land in order, so all but the D - 1 youngest (each
+    // frame is one load, two with a mask) have landed after vmcnt(that many); draining: vmcnt(0)
+    bool have[D];
+#pragma unroll
+    for (int s = 0; s < D; ++s) have[s] = false;
+    bool more = true;
+    while (more) {
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        if (!more) break;
+        if (have[s]) {
+          if (MASK) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(D - 1) : "memory");
+          count(s);
+        }
+        more = have[s] = refill();
+        if (more) {
+          const int j = (int)__builtin_ctzll(todo);
+          todo &= todo - 1;
+          issue(s, j);
+        }
       }
     }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-  for (int s = 0; s < D; ++s)
-    if (have[s]) count(s);
+    for (int s = 0; s < D; ++s)
+      if (have[s]) count(s);
+  };
+  pass(std::true_type{});
+  pass(std::false_type{});
   cnt.finish(p, X, Y0);
 }
 
