@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   const int W = (int)p.W, H = (int)p.H;
   const uint64_t fbytes = (uint64_t)H * (uint64_t)W;
   const int lrow = (int)(lane >> 2), lpiece = (int)(lane & 3u) * 16;
-  const uint32_t lane_off = (uint32_t)(lrow * W + lpiece);  // this lane's 16 bytes within the R x 64 window
+  const uint32_t lane_off = (uint32_t)lrow * (uint32_t)W + (uint32_t)lpiece;  // this lane's 16 bytes within the R x 64 window
 
   BlitCounters<R> cnt;
   cnt.clear();
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
           for (int r = 0; r < R; ++r)
             if ((uint32_t)(fy0 + r) < (uint32_t)H) rows |= 1u << r;
         }
-        w_base = (uint64_t)rec.x * fbytes + (uint64_t)(uint32_t)((FULL ? fy0 * W : 0) + sxc);
+        w_base = (uint64_t)rec.x * fbytes + (uint64_t)((FULL ? (uint32_t)fy0 * (uint32_t)W : 0u) + (uint32_t)sxc);  // (W H < 2^32)
         w_info = (uint32_t)(sx - sxc + 64) | rows << 16;
         w_fy0 = fy0;
         todo = __builtin_amdgcn_ballot_w64(live && full == FULL && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
       if (!FULL) {
         const int fy0 = __builtin_amdgcn_readlane(w_fy0, j);
         const int row = min(max(fy0 + lrow, 0), H - 1);  // rows outside the frame: a valid address, not counted
-        off = wb + (uint64_t)(uint32_t)(row * W + lpiece);
+        off = wb + (uint64_t)((uint32_t)row * (uint32_t)W + (uint32_t)lpiece);
       }
       if (R == 16 || lane < 4u * R) {
         __builtin_amdgcn_global_load_lds((blit_glb_ptr)(p.frames + off), (blit_lds_ptr)&ring[wv][s][0][0], 16, 0, 0);
