@@ -31,3 +31,21 @@ for sh in shapes:
     if ref is None:
         ref = got
     print(f"{sh}: {ms:.3f} ms per call  same_as_first={bool(torch.equal(got, ref))}  sum={int(got.view(torch.uint8).sum())}", flush=True)
+
+# the canvas consumers beside it: fgm_blend (32 B read + 2 B written per dot) and fgm_merge
+cw, ch, zx, zy = ctx.fgm_extent(pos)
+for _ in range(2):
+    img, mask = ctx.fgm_blend(canvas)
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10):
+    img, mask = ctx.fgm_blend(canvas)
+torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 10 * 1e3
+print(f"fgm_blend: {ms:.3f} ms per call, {ch * cw * 34 / ms / 1e6:.0f} GB/s ({ch}x{cw} dots, 34 B each)", flush=True)
+big = torch.zeros((ch, cw, 16), dtype=torch.int16, device="cuda")
+for _ in range(2):
+    ctx.fgm_merge(big, canvas, (0, 0))
+torch.cuda.synchronize(); t = time.perf_counter()
+for _ in range(10):
+    ctx.fgm_merge(big, canvas, (0, 0))
+torch.cuda.synchronize(); ms = (time.perf_counter() - t) / 10 * 1e3
+print(f"fgm_merge: {ms:.3f} ms per call, {ch * cw * 96 / ms / 1e6:.0f} GB/s ({ch}x{cw} dots, 32 B read + 32 B read + 32 B written)", flush=True)
