@@ -98,6 +98,30 @@ OPD(k_max_u32_dpp_quad, "v_max_u32_dpp", "quad_perm:[1,0,3,2]")
 OPD(k_max_u32_sdwa, "v_max_u32_sdwa", "dst_sel:DWORD src0_sel:BYTE_1 src1_sel:BYTE_2")
 OPD(k_max_u16_sdwa, "v_max_u16_sdwa", "dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:WORD_1 src1_sel:WORD_1")
 
+// 64-bit forms: %0 is a register pair
+#define OP64(NAME, TEXT)                                                                       \
+  __global__ void NAME(unsigned* out, int iters) {                                             \
+    unsigned long long a = threadIdx.x, b = a * 3 + 1, c = a * 5 + 2, d = a * 7 + 3;           \
+    unsigned x = threadIdx.x & 31, y = x + 1;                                                  \
+    for (int it = 0; it < iters; ++it) {                                                       \
+      _Pragma("unroll") for (int u = 0; u < 32; ++u) {                                         \
+        asm volatile(TEXT : "+v"(a) : "v"(x), "v"(y) : "vcc");                                 \
+        asm volatile(TEXT : "+v"(b) : "v"(y), "v"(x) : "vcc");                                 \
+        asm volatile(TEXT : "+v"(c) : "v"(x), "v"(y) : "vcc");                                 \
+        asm volatile(TEXT : "+v"(d) : "v"(y), "v"(x) : "vcc");                                 \
+      }                                                                                        \
+    }                                                                                          \
+    out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(a ^ b ^ c ^ d);                    \
+  }
+OP64(k_lshlrev_b64, "v_lshlrev_b64 %0, %1, %0")
+OP64(k_mad_u64_u32, "v_mad_u64_u32 %0, vcc, %1, %2, %0")
+OP64(k_lshl_add_u64, "v_lshl_add_u64 %0, %0, 1, %0")
+OP2(k_mul_lo_u32, "v_mul_lo_u32")
+OP2(k_mul_hi_u32, "v_mul_hi_u32")
+OP2(k_mul_u32_u24, "v_mul_u32_u24")
+OP3(k_mad_u32_u24, "v_mad_u32_u24")
+OP3(k_bitop3, "v_xad_u32")
+
 typedef void (*kern_t)(unsigned*, int);
 struct Entry { const char* name; kern_t k; };
 
@@ -114,7 +138,8 @@ int main() {
       E(k_pk_max_u16), E(k_pk_min_u16), E(k_pk_add_u16), E(k_pk_max_i16), E(k_pk_max_f16),
       E(k_max_u16), E(k_max_f32), E(k_add_f32), E(k_pk_add_f32x),
       E(k_max_u32_dpp_shr), E(k_max_u32_dpp_row), E(k_max_u32_dpp_quad), E(k_max_u32_sdwa),
-      E(k_max_u16_sdwa),
+      E(k_max_u16_sdwa), E(k_lshlrev_b64), E(k_mad_u64_u32), E(k_lshl_add_u64), E(k_mul_lo_u32), E(k_mul_hi_u32),
+      E(k_mul_u32_u24), E(k_mad_u32_u24), E(k_bitop3),
   };
   hipEvent_t a, b; (void)hipEventCreate(&a); (void)hipEventCreate(&b);
   for (auto& e : es) {
