@@ -115,6 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU")
     ap.add_argument("--dens", type=int, default=DENS)
+    ap.add_argument("--lanes", type=int, default=2, help="blocks in flight (AlignerPipe); 1: one stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-frames", type=int, default=10000)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the "
@@ -124,7 +125,7 @@ def main():
     import torch
 
     from remap_amd import lib as L
-    from remap_amd.pipeline import Aligner, shard_range
+    from remap_amd.pipeline import Aligner, AlignerPipe, shard_range
     from remap_amd.synth import scroller_v1
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -167,6 +168,10 @@ def main():
     frames = torch.from_numpy(frames_host).to(dev)
 
     al = Aligner(W, H, kmax=2048, device=local_rank, dist=dist)
+    # the headline: blocks taken in turn by two lanes (streams), the small kernels of block t beside
+    # the extraction of block t + 1 (AlignerPipe); `al` (one lane, the default stream) serves the
+    # checks and the figures reported beside the headline
+    pipe = AlignerPipe(W, H, kmax=2048, device=local_rank, dist=dist, lanes=args.lanes)
 
     def barrier():
         if dist is not None:
@@ -193,20 +198,37 @@ def main():
     # The K timed steps are enqueued back to back (defer=True: a stream of blocks, as collect
     # sees it); the host waits ONCE, inside the timed region: finish() returns the last step's
     # fragment count and raises if any of the K steps overflowed a table or a matcher limit.
-    al.ctx.set_timing(2)
+    for _ in range(max(args.warmup, 2 * args.lanes)):
+        pipe.align(frames, n_total=n_total)
+    pipe.finish()
+    for lane in pipe.lanes:
+        lane.ctx.set_timing(2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = al.align(frames, n_total=n_total, defer=True)
-    nfrag_timed = al.finish()
+        out = pipe.align(frames, n_total=n_total)
+    nfrag_timed = pipe.finish()
     barrier()
     dt = time.perf_counter() - t0
     # ... and what they computed is the ground truth too (last step's outputs)
     dx2, mt2, ps2, fg2 = (out[k].cpu().numpy() for k in ("dxdy", "matched", "pos", "frag"))
     exact = bool(exact and mt2[first:].all() and (dx2[first:] == truth[lo + first:hi]).all()
                  and (ps2[:, 0] == cam_x[lo:hi]).all() and (ps2[:, 1] == 0).all() and (fg2 == 0).all() and nfrag_timed == 1)
-    ms_kpe = al.ctx.kernel_ms("kpe_main")          # average per launch (the timing track of kpe_mf / kpe_main)
-    launches_per_step = al.ctx.kernel_launches("kpe_main") / max(1, args.steps)
+    # average per launch over the timed region (the timing track of kpe_mf / kpe_main), all lanes
+    nl = [lane.ctx.kernel_launches("kpe_main") for lane in pipe.lanes]
+    ms_kpe = sum(lane.ctx.kernel_ms("kpe_main") * k for lane, k in zip(pipe.lanes, nl) if k) / max(1, sum(nl))
+    launches_per_step = sum(nl) / max(1, args.steps)
+    for lane in pipe.lanes:
+        lane.ctx.set_timing(False)
+    # the same steps on ONE lane (round 2a-2e's figure), for reference
+    al.align(frames, n_total=n_total)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        al.align(frames, n_total=n_total, defer=True)
+    al.finish()
+    barrier()
+    dt_one = time.perf_counter() - t0
     al.ctx.set_timing(True)
     for _ in range(3):
         al.align(frames, n_total=n_total)
@@ -273,10 +295,10 @@ def main():
     torch_copy_gbs = copy_rate(lambda: stage.copy_(frames))
     del pinned, stage
 
-    tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+    tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0, dt_one], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, dtb, dth, dtc, bad = (float(v) for v in tmax)
+    dt, dtb, dth, dtc, bad, dt_one = (float(v) for v in tmax)
     exact = bad == 0.0  # on every rank
 
     if rank == 0:
@@ -306,8 +328,11 @@ def main():
                                    f"kpe+kpm+frc HIP kernels, inputs resident in HBM",
                        "frames_total": n_total, "keypoints_per_frame": ktot / n_local,
                        "parallelism": f"frame-sharded x{world}" + (" + RCCL all-gather of boundary tables and 16-B scan summaries"
-                                                                   if world > 1 else "")},
+                                                                   if world > 1 else "")
+                                      + (f", {args.lanes} blocks in flight per GPU (the small kernels of block t beside the extraction of block t+1)"
+                                         if args.lanes > 1 else "")},
             "offsets_bit_exact_vs_truth": exact,
+            "frames_per_s_one_block_in_flight": n_total * args.steps / dt_one,
             "frames_per_s_with_blit": n_total * nb / dtb,
             "frames_per_s_with_blit_and_codec": n_total * nb / dtc,
             "frames_per_s_host_fed": n_total * nh / dth,
@@ -340,6 +365,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     al.close()
+    pipe.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -166,7 +166,7 @@ class Aligner:
             self._bufs[name] = b
         return b
 
-    def align(self, frames, n_total=None, blit=False, check=True, compress=False, defer=False):
+    def align(self, frames, n_total=None, blit=False, check=True, compress=False, defer=False, kpe_gate=None):
         """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
 
         Returns a dict with device tensors for the LOCAL block (frames lo..hi of the stream):
@@ -194,7 +194,11 @@ class Aligner:
         median = self._buf("median", frames.shape, t.uint8)
         desc = self._buf("desc", (n, self.kmax, L.DESC_BYTES), t.uint8)
         kcount = self._buf("kcount", (n,), t.int32)
+        if kpe_gate is not None:  # (AlignerPipe: the extraction kernels of consecutive steps take turns)
+            kpe_gate[0]()
         ctx.kpe(frames, median, desc, kcount)
+        if kpe_gate is not None:
+            kpe_gate[1]()
         halo = None
         if self.world > 1:
             tabs, cnts = gather_boundary_tables(desc[n - 1], kcount[n - 1:n], self.dist, self.group)
@@ -374,3 +378,69 @@ class Aligner:
 
     def close(self):
         self.ctx.close()
+
+
+class AlignerPipe:
+    """Blocks of a stream in flight on `lanes` Aligners (each with its own HIP stream and
+    workspaces), taken in turn.
+
+    A step of the hot path is one VALU-bound kernel (kpe_mf, two thirds of the step) followed by
+    a chain of ~14 small latency-bound ones (table, kpm_build*, kpm_match*, declare, scan) that
+    leave most of the chip idle.  With two lanes the chain of block t runs beside the extraction
+    of block t + 1.  The extraction kernels themselves take turns (an event between the lanes):
+    two of them side by side only share the chip, and each would take twice as long.
+
+    Every block is a step of its own, as with `Aligner.align(defer=True)`; `finish()` waits for
+    all lanes and returns the fragment count of the last block (raises if any block overflowed).
+    With several ranks the lanes share one process group: its collectives run in issue order,
+    which is the same on every rank."""
+
+    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2):
+        import torch
+
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        self.lanes = []
+        for s in self.streams:
+            with torch.cuda.stream(s):  # (a Context adopts the stream that is current when it is made)
+                self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=group))
+        self._turn = 0
+        self._kpe_done = None
+
+    def align(self, frames, n_total=None):
+        t = self.torch
+        i = self._turn % len(self.lanes)
+        self._turn += 1
+        s = self.streams[i]
+        s.wait_stream(t.cuda.current_stream(self.device))  # the frames were produced there
+
+        def before_kpe():
+            if self._kpe_done is not None:
+                s.wait_event(self._kpe_done)
+
+        def after_kpe():
+            ev = t.cuda.Event()
+            ev.record(s)
+            self._kpe_done = ev
+
+        with t.cuda.stream(s):
+            return self.lanes[i].align(frames, n_total=n_total, defer=True,
+                                       kpe_gate=(before_kpe, after_kpe) if len(self.lanes) > 1 else None)
+
+    def finish(self):
+        t = self.torch
+        used = min(self._turn, len(self.lanes))
+        last = (self._turn - 1) % len(self.lanes) if self._turn else 0
+        nfrag = None
+        for i in range(used):
+            with t.cuda.stream(self.streams[i]):
+                r = self.lanes[i].finish()
+            if i == last:
+                nfrag = r
+            t.cuda.current_stream(self.device).wait_stream(self.streams[i])
+        return nfrag
+
+    def close(self):
+        for a in self.lanes:
+            a.close()

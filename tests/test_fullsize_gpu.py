@@ -84,3 +84,53 @@ def test_deferred_steps_equal_synchronous_ones(gpu):
     with pytest.raises(L.RemapError):
         al.finish()
     al.close()
+
+
+def test_blocks_in_flight_equal_blocks_one_by_one(gpu):
+    """AlignerPipe: different blocks taken in turn by two (three) lanes on their own streams, the
+    extraction kernels gated by events — every block's outputs equal the synchronous Aligner's;
+    finish() reports the last block's fragment count and an overflow of ANY block."""
+    import torch
+
+    from remap_amd.pipeline import Aligner, AlignerPipe
+
+    blocks = []
+    for k, (n, dens) in enumerate(((300, 100), (500, 200), (200, 60), (400, 150), (350, 100))):
+        fr, _ = scroller_v1(n, dens=dens, cam_seed=100 + k)
+        fr = fr.copy()
+        if k % 2:
+            fr[n // 3] = 6  # a fragment break
+        blocks.append(torch.from_numpy(fr).cuda())
+    al = Aligner(320, 240, kmax=2048)
+    want = []
+    for b in blocks:
+        o = al.align(b)
+        want.append(({k: o[k].clone() for k in ("dxdy", "matched", "pos", "frag", "kcount", "median")}, o["nfrag"]))
+    al.close()
+    for lanes in (2, 3, 1):
+        pipe = AlignerPipe(320, 240, kmax=2048, lanes=lanes)
+        for rep in range(2):
+            outs = [pipe.align(b) for b in blocks[:lanes]]  # (a lane's buffers are reused by its next block)
+            assert pipe.finish() == want[lanes - 1][1]
+            for o, (w, _) in zip(outs, want):
+                for k, v in w.items():
+                    assert torch.equal(o[k], v), (lanes, k)
+        # more blocks than lanes: each result is read before its lane is used again
+        for i, b in enumerate(blocks):
+            o = pipe.align(b)
+            if i >= lanes - 1:
+                pass
+            torch.cuda.synchronize()
+            for k, v in want[i][0].items():
+                assert torch.equal(o[k], v), (lanes, i, k)
+        assert pipe.finish() == want[-1][1]
+        pipe.close()
+    rng = np.random.default_rng(1)
+    noise = torch.from_numpy(rng.integers(0, 16, size=(4, 240, 320), dtype=np.uint8)).cuda()
+    pipe = AlignerPipe(320, 240, kmax=256, lanes=2)
+    pipe.align(noise)
+    pipe.align(blocks[0][:4].contiguous())
+    pipe.align(blocks[0][:4].contiguous())
+    with pytest.raises(L.RemapError):
+        pipe.finish()
+    pipe.close()

@@ -89,9 +89,22 @@ def _worker_align(rank, world, port, q):
     lo, hi = shard_range(n, rank, world)
     al = Aligner(320, 240, kmax=2048, dist=dist)
     out = al.align(torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda(), n_total=n, blit=True)
-    q.put((rank, lo, hi, out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy(), out["pos"].cpu().numpy(),
-           out["frag"].cpu().numpy(), out["pos_all"].cpu().numpy(), out["frag_all"].cpu().numpy(), out["nfrag"]))
+    res = (rank, lo, hi, out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy(), out["pos"].cpu().numpy(),
+           out["frag"].cpu().numpy(), out["pos_all"].cpu().numpy(), out["frag_all"].cpu().numpy(), out["nfrag"])
     al.close()
+    # the same block through two lanes in flight (AlignerPipe shares the process group): three
+    # steps, same offsets / positions / fragment ids / fragment count as the one above
+    from remap_amd.pipeline import AlignerPipe
+
+    pipe = AlignerPipe(320, 240, kmax=2048, dist=dist, lanes=2)
+    local = torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda()
+    outs = [pipe.align(local, n_total=n) for _ in range(3)]
+    nf = pipe.finish()
+    same = nf == res[9]
+    for o in outs[1:]:
+        same = same and all(np.array_equal(o[k].cpu().numpy(), v) for k, v in (("dxdy", res[3]), ("matched", res[4]), ("pos", res[5]), ("frag", res[6])))
+    pipe.close()
+    q.put(res + (bool(same),))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -133,8 +146,9 @@ def test_four_ranks_equal_single_process_bit_for_bit(gpu):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, lo, hi, dxdy, matched, pos, frag, pos_all, frag_all, nf in res:
+    for rank, lo, hi, dxdy, matched, pos, frag, pos_all, frag_all, nf, pipe_same in res:
         first = 1 if rank == 0 else 0
+        assert pipe_same, rank
         assert np.array_equal(matched, want["matched"][lo:hi]), rank
         assert np.array_equal(dxdy[first:], want["dxdy"][lo + first:hi]), rank
         assert np.array_equal(pos, want["pos"][lo:hi]) and np.array_equal(frag, want["frag"][lo:hi]), rank
