@@ -407,6 +407,7 @@ class AlignerPipe:
                 self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=group))
         self._turn = 0
         self._kpe_done = None
+        self._pending = [None] * lanes
 
     def align(self, frames, n_total=None):
         t = self.torch
@@ -440,6 +441,51 @@ class AlignerPipe:
                 nfrag = r
             t.cuda.current_stream(self.device).wait_stream(self.streams[i])
         return nfrag
+
+    # ---- blocks with host-side stages (canvas blit, codec): submit / drain -------------------------
+    def submit(self, frames, n_total=None, blit=False, compress=False):
+        """Enqueue the alignment of one block on the next lane; the block that lane held before is
+        completed first (status check, fragment count and — if asked for when IT was submitted —
+        codec and canvas blit, whose extents need the positions on the host) and returned, else
+        None.  The host waits for a block that was enqueued `lanes` submits ago while the other
+        lanes keep the device busy; the blit of block t runs beside the extraction of block t + 1."""
+        i = self._turn % len(self.lanes)
+        done = self._complete(i)
+        out = self.align(frames, n_total=n_total)
+        self._pending[i] = (out, frames, blit, compress)
+        return done
+
+    def drain(self):
+        """Complete what is still in flight, oldest first; returns those blocks' results."""
+        res = []
+        k = len(self.lanes)
+        for j in range(k):
+            r = self._complete((self._turn + j) % k)
+            if r is not None:
+                res.append(r)
+        for s in self.streams:
+            self.torch.cuda.current_stream(self.device).wait_stream(s)
+        return res
+
+    def _complete(self, i):
+        pend = self._pending[i]
+        if pend is None:
+            return None
+        self._pending[i] = None
+        out, frames, blit, compress = pend
+        lane = self.lanes[i]
+        t = self.torch
+        with t.cuda.stream(self.streams[i]):
+            out["nfrag"] = lane.finish()
+            n = frames.shape[0]
+            if compress:
+                out["nic_image"] = lane.ctx.nic_compress(frames.reshape(n, -1), pack=False)
+                out["nic_median"] = lane.ctx.nic_compress(out["median"].reshape(n, -1), pack=False)
+                lane.ctx._chk(lane.ctx.lib.rmx_nic_status(lane.ctx.h), "rmx_nic_status")
+            if blit:
+                lane.gather_positions(out)
+                out["canvases"] = lane.blit(frames, out["pos_all"], out["frag_all"], out["lo"], out["hi"])
+        return out
 
     def close(self):
         for a in self.lanes:

@@ -134,3 +134,50 @@ def test_blocks_in_flight_equal_blocks_one_by_one(gpu):
     with pytest.raises(L.RemapError):
         pipe.finish()
     pipe.close()
+
+
+def test_submit_drain_blits_equal_synchronous_steps(gpu):
+    """AlignerPipe.submit / drain: blocks with a canvas blit (and the codec) in flight on two
+    lanes — every block's canvases, blobs and fragment count equal the synchronous Aligner's."""
+    import torch
+
+    from remap_amd.pipeline import Aligner, AlignerPipe
+
+    blocks = []
+    for k, (n, dens) in enumerate(((300, 100), (260, 200), (200, 60), (320, 150))):
+        fr, _ = scroller_v1(n, dens=dens, cam_seed=200 + k)
+        fr = fr.copy()
+        if k % 2 == 0:
+            fr[n // 2] = 6  # a fragment break: two canvases
+        blocks.append(torch.from_numpy(fr).cuda())
+    al = Aligner(320, 240, kmax=2048)
+    want = []
+    for b in blocks:
+        o = al.align(b, blit=True, compress=True)
+        want.append(dict(nfrag=o["nfrag"], pos=o["pos"].clone(),
+                         canv={f: (c.clone(), z, g) for f, (c, z, g) in o["canvases"].items()},
+                         sizes=o["nic_image"][1].clone(), msizes=o["nic_median"][1].clone(), blobs=o["nic_median"][0].clone()))
+    al.close()
+    pipe = AlignerPipe(320, 240, kmax=2048, lanes=2)
+    got = []
+
+    def keep(r):  # (a lane's buffers are reused by its next block: compare right away)
+        if r is None:
+            return
+        w = want[len(got)]
+        assert r["nfrag"] == w["nfrag"] and torch.equal(r["pos"], w["pos"])
+        assert set(r["canvases"]) == set(w["canv"])
+        for f, (c, z, g) in r["canvases"].items():
+            assert z == w["canv"][f][1] and g == w["canv"][f][2] and torch.equal(c, w["canv"][f][0]), f
+        assert torch.equal(r["nic_image"][1], w["sizes"]) and torch.equal(r["nic_median"][1], w["msizes"])
+        valid = torch.arange(w["blobs"].shape[1], device="cuda")[None, :] < w["msizes"][:, None]  # (bytes past a blob's size are padding)
+        assert torch.equal(r["nic_median"][0] * valid, w["blobs"] * valid)
+        got.append(True)
+
+    for b in blocks:
+        keep(pipe.submit(b, blit=True, compress=True))
+        torch.cuda.synchronize()
+    for r in pipe.drain():
+        keep(r)
+    assert len(got) == len(blocks)
+    pipe.close()
