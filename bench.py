@@ -222,6 +222,7 @@ def main():
         lane.ctx.set_timing(False)
     # the same steps on ONE lane (round 2a-2e's figure), for reference
     al.align(frames, n_total=n_total)
+    al.ctx.set_timing(2)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -229,6 +230,7 @@ def main():
     al.finish()
     barrier()
     dt_one = time.perf_counter() - t0
+    ms_kpe_one = al.ctx.kernel_ms("kpe_main")  # the extraction kernel with the chip to itself
     al.ctx.set_timing(True)
     for _ in range(3):
         al.align(frames, n_total=n_total)
@@ -359,6 +361,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "kpe_mf (whole keypoint extraction: streaming 3x3 pass + 5x5 finish of the workgroup's own "
                                    "candidates; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "one_block_in_flight": {"note": "the same kernel with the chip to itself (single stream, the K steps timed again); "
+                                                         "with two blocks in flight the small kpm kernels of the previous block run beside it",
+                                                 "kpe_mf_ms": ms_kpe_one,
+                                                 "frac": alg_bytes / (ms_kpe_one * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_kpe_one > 0 else None},
                          "pair": {"note": "two-kernel form of rounds 1-2a on this box, same algorithmic bytes",
                                   "kpe_main_ms": pair["kpe_main"], "kpe_finish_ms": pair["kpe_finish"],
                                   "kpe_main_alone_frac": alg_bytes / (pair["kpe_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS if pair["kpe_main"] > 0 else None,
