@@ -157,6 +157,7 @@ class Aligner:
         self.rank = self.dist.get_rank(group) if self.dist else 0
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self._bufs = {}
+        self.blit_gate = None
 
     def _buf(self, name, shape, dtype):
         t = self.torch
@@ -306,6 +307,8 @@ class Aligner:
         if c is None or tuple(c.shape) != (ch, cw, 16):
             c = t.empty((ch, cw, 16), dtype=t.int16, device=self.ctx.device)
             self._bufs[key] = c
+        if self.blit_gate is not None:  # (AlignerPipe: the blit kernels wait for the other lane's extraction)
+            self.blit_gate()
         c.zero_()
         self.ctx.fgm_blit(frames[fa:fb], pos[pa:pb], c, (zx, zy), frag_id=frag, fragment=int(fid))
         return (c, (zx, zy), (gw, gh, (gzx, gzy)))
@@ -484,7 +487,15 @@ class AlignerPipe:
                 lane.ctx._chk(lane.ctx.lib.rmx_nic_status(lane.ctx.h), "rmx_nic_status")
             if blit:
                 lane.gather_positions(out)
+                # the blit goes beside the other lane's small kernels, not beside its extraction
+                # kernel (together those two take the sum of their times): it waits for the
+                # extraction that is under way, this lane's next one follows it in stream order
+                # (the wait goes right before the blit's kernels: the host-side stage — positions to
+                # the host, extents — runs while that extraction kernel does)
+                ev, s = self._kpe_done, self.streams[i]
+                lane.blit_gate = (lambda: s.wait_event(ev)) if (ev is not None and len(self.lanes) > 1) else None
                 out["canvases"] = lane.blit(frames, out["pos_all"], out["frag_all"], out["lo"], out["hi"])
+                lane.blit_gate = None
         return out
 
     def close(self):
