@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
 // ---- fgm::fragment::blit(pos, image, …) (fgm.hpp:87-97,176-188) -------------------------------
 // ++canvas[y+py-zy][x+px-zx][pixel] with uint16 wraparound, for a whole batch of frames.
 // Output-centric, counters in REGISTERS: a wave owns 64 canvas columns x R rows, a lane one
-// column of them.  It walks the frames binned to its tile column; of every frame that covers
-// the tile a lane loads its R pixels (one byte each) and counts them in sixteen 4-bit counters
-// per pixel (two dwords: `v_lshlrev_b64` of a one by 4 x colour, two adds).  Every 15 frames
-// the nibbles are folded into 8-bit counters (four dwords per pixel), every 255 frames — and at
-// the end — those into the canvas with its uint16 wraparound (fgm.hpp:14).  No LDS, no atomics,
-// no barriers; every frame byte is read once (by the tile it lands in), every canvas dot is
-// read and written once per 255 covering frames.  Lanes left or right of a frame shift a zero
-// instead of a one: the frame's edges cost nothing per pixel.
+// column of them.  It walks the frames binned to its group of tile columns; of every frame that
+// covers the tile a lane takes its R pixels (one byte each; how they get there: at the kernels)
+// and counts them in sixteen 4-bit counters per pixel (two dwords: `v_lshlrev_b64` of a one by
+// 4 x colour, two adds).  Every 15 frames the nibbles are folded into 8-bit counters (four dwords
+// per pixel), every 255 frames — and at the end — those into the canvas with its uint16
+// wraparound (fgm.hpp:14).  No atomics, no barriers; every canvas dot is read and written once
+// per 255 covering frames.  Lanes left or right of a frame shift a zero instead of a one: the
+// frame's edges cost nothing per pixel.
 struct BlitParams {
   const uint8_t* frames;
   const uint8_t* mask;   // optional, same layout as frames: pixels with a non-zero byte are not counted (fgm.hpp:71-86)
