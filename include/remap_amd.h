@@ -181,6 +181,8 @@ int rmx_frc_scan(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint
  *                        device, rank order) and moves the block into place: pos and frag_id
  *                        become what rmx_frc_scan over the whole stream gives (frc.hpp:109-115);
  *   rmx_frc_finish       synchronises once; *nfrag = fragments of the whole stream.
+ * With ONE rank rmx_frc_apply_blocks may be left out: a block that is the whole stream is already in
+ * place, and rmx_frc_scan_block leaves its fragment count for rmx_frc_finish.
  * Bit 1 of summary[0] tells the other ranks that this block has tickets left to rmx_kpm_resolve:
  * after rmx_frc_finish, rmx_kpm_status reports flag 128 on EVERY rank if it does on one, so the
  * ranks resolve (a no-op where nothing is left) and scan again together. */

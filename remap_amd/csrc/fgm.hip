@@ -12,7 +12,7 @@ struct ScanParams {
   const uint8_t* matched;
   int32_t* pos;
   uint32_t* frag;
-  int32_t* carry;  // device: [0..1] position, [2] fragment id (out)
+  int32_t* carry;  // device: [0..1] position, [2] fragment id (out); with a summary also [3] fragments, [4] pending (= frc_apply's output)
   uint32_t n;
   uint32_t first_is_start;
   int32_t carry_in[3];  // the carry on entry (by value: no upload)
@@ -121,10 +121,15 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
     p.carry[1] = s_carry.y;
     p.carry[2] = s_carry.c;
     if (p.summary) {
-      p.summary[0] = ((p.first_is_start || s_carry.c > 0) ? 1 : 0) | ((p.kpm_status && (*p.kpm_status & 128u)) ? 2 : 0);
+      const int32_t pending = (p.kpm_status && (*p.kpm_status & 128u)) ? 2 : 0;
+      p.summary[0] = ((p.first_is_start || s_carry.c > 0) ? 1 : 0) | pending;
       p.summary[1] = s_carry.x;
       p.summary[2] = s_carry.y;
       p.summary[3] = s_carry.c;
+      // what frc_apply leaves for rmx_frc_finish when this block is the whole stream (one rank:
+      // no apply launch needed; with several ranks frc_apply overwrites both words)
+      p.carry[3] = s_carry.c + 1;
+      p.carry[4] = pending;
     }
   }
 }

@@ -210,8 +210,7 @@ class Aligner:
             pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)  # synchronises
             nfrag = carry[1] + 1
         elif self.world == 1:
-            pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=True)
-            ctx.frc_apply_blocks(mine, 0, 1, pos, frag)  # (leaves the fragment count for finish())
+            pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=True)  # (leaves the fragment count for finish())
             nfrag = None
         else:
             # every rank scans its block on its own; the blocks' 16-byte summaries (did a fragment
