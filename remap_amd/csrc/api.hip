@@ -31,7 +31,10 @@ struct rmx_ctx {
   Bands bands{};
   // workspace (device)
   RawDesc* raw = nullptr;
-  uint32_t* kraw = nullptr;
+  uint32_t* kraw = nullptr;    // per-frame append counters of the current batch: one of two buffers (2 x n_cap)
+  uint32_t* kraw_base = nullptr;   // (the allocation)
+  uint32_t* kraw_other = nullptr;  // the other one; its first kraw_clean entries are zero (cleared by the table kernels)
+  uint32_t kraw_clean = 0;
   uint32_t* tflag = nullptr;  // per frame: left to kpe_table_rest
   uint32_t* cand = nullptr;  // candidate bit plane, n * ceil(H/8) * W/4 dwords
   uint32_t* tab_ws = nullptr;  // kpe_table_big (kmax > 16 384): 2 * ceil(W*H/32) dwords per frame
@@ -161,19 +164,22 @@ hipError_t launch_fused(const rmx_ctx::FusedPlan& pl, const KpeFusedParams& kp, 
 int ensure_workspace(rmx_ctx* ctx, uint32_t n) {
   if (n <= ctx->n_cap) return RMX_OK;
   if (ctx->raw) (void)hipFree(ctx->raw);
-  if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->kraw_base) (void)hipFree(ctx->kraw_base);
   if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->tab_ws) (void)hipFree(ctx->tab_ws);
   ctx->tab_ws = nullptr;
   ctx->raw = nullptr;
-  ctx->kraw = nullptr;
+  ctx->kraw = ctx->kraw_base = ctx->kraw_other = nullptr;
   ctx->tflag = nullptr;
   ctx->cand = nullptr;
   ctx->n_cap = 0;
   const size_t cand_bytes = ctx->fused.ok ? 256 : (size_t)n * ((ctx->H + 7) / 8) * ((ctx->W + 3) / 4) * sizeof(uint32_t);
   RMX_HIP(hipMalloc(&ctx->raw, (size_t)n * ctx->kmax * sizeof(RawDesc)));
-  RMX_HIP(hipMalloc(&ctx->kraw, (size_t)n * sizeof(uint32_t)));
+  RMX_HIP(hipMalloc(&ctx->kraw_base, 2 * (size_t)n * sizeof(uint32_t)));
+  ctx->kraw = ctx->kraw_base;
+  ctx->kraw_other = ctx->kraw_base + n;
+  ctx->kraw_clean = 0;
   RMX_HIP(hipMalloc(&ctx->tflag, (size_t)n * sizeof(uint32_t)));
   RMX_HIP(hipMalloc(&ctx->cand, cand_bytes));
   if (ctx->kmax > KPE_KMAX_LDS) RMX_HIP(hipMalloc(&ctx->tab_ws, (size_t)n * 2 * (((size_t)ctx->W * ctx->H + 31) / 32) * sizeof(uint32_t)));
@@ -287,7 +293,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->raw) (void)hipFree(ctx->raw);
   if (ctx->tflag) (void)hipFree(ctx->tflag);
-  if (ctx->kraw) (void)hipFree(ctx->kraw);
+  if (ctx->kraw_base) (void)hipFree(ctx->kraw_base);
   if (ctx->cand) (void)hipFree(ctx->cand);
   if (ctx->tab_ws) (void)hipFree(ctx->tab_ws);
   if (ctx->status) (void)hipFree(ctx->status);
@@ -465,7 +471,12 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   RMX_HIP(hipSetDevice(ctx->device));
   if (int rc = ensure_workspace(ctx, n)) return rc;
   ctx->n_last = n;
-  RMX_HIP(hipMemsetAsync(ctx->kraw, 0, (size_t)n * sizeof(uint32_t), ctx->stream));
+  // the append counters: the buffer the previous batch's table kernels cleared (a memset only
+  // for what they did not reach: the first batch, a longer batch)
+  std::swap(ctx->kraw, ctx->kraw_other);
+  if (ctx->kraw_clean < n)
+    RMX_HIP(hipMemsetAsync(ctx->kraw + ctx->kraw_clean, 0, (size_t)(n - ctx->kraw_clean) * sizeof(uint32_t), ctx->stream));
+  ctx->kraw_clean = n;  // (of the other buffer, once this batch's table kernels have run)
   // Optional sub-batching (RMX_SUB_MIB): keeping frames + medians + candidate plane inside
   // the 256 MiB Infinity Cache between the streaming and the finishing pass was measured
   // SLOWER at every size (small launches cost more than the re-reads), so the default is
@@ -571,6 +582,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   TableParams tp{};
   tp.raw = ctx->raw;
   tp.kcount = ctx->kraw;
+  tp.knext = ctx->kraw_other;
   tp.desc = desc;
   tp.kout = kcount;
   tp.status = ctx->status;

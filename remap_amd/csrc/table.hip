@@ -22,6 +22,7 @@ struct TableParams {
   uint32_t rank_words;  // ceil(W * H / 32) if the rank bitmap fits the launch's LDS, else 0
   uint32_t wave_ok;     // frame <= 1024 x 1024 and kmax <= 2048: (x, y, index) fit a 32-bit sort key
   uint32_t* left;       // n flags: frame not done by the wave pass
+  uint32_t* knext;      // the NEXT batch's append counters (the other of two buffers): cleared here, no memset launch
 };
 
 // In-LDS bitonic sort of n2 (power of two) 64-bit keys, ascending; blockDim.x threads.
@@ -166,6 +167,7 @@ __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
   const uint32_t f = blockIdx.x * 4 + wave;
   if (f >= p.n) return;
   uint32_t k = p.kcount[f];
+  if (lane == 0) p.knext[f] = 0;
   if (k > p.kmax) k = p.kmax;
   const bool mine = p.wave_ok && k <= 256;
   if (lane == 0) p.left[f] = mine ? 0u : 1u;
@@ -217,6 +219,7 @@ __global__ __launch_bounds__(1024) void kpe_table_big(TableParams p, uint32_t* s
   __shared__ uint32_t s_wave[16];
   const uint32_t f = blockIdx.x, tid = threadIdx.x;
   uint32_t k = p.kcount[f];
+  if (tid == 0) p.knext[f] = 0;
   if (k > p.kmax) k = p.kmax;  // overflow already flagged
   const RawDesc* raw = p.raw + (size_t)f * p.kmax;
   rmx_desc* out = p.desc + (size_t)f * p.kmax;
