@@ -317,6 +317,11 @@ int rmx_kernel_launches(rmx_ctx* ctx, const char* kernel, uint32_t* launches);
  * Synchronises. */
 int rmx_debug_umap_order(rmx_ctx* ctx, const uint64_t* hashes, uint32_t n, uint32_t* order);
 
+/* Diagnostic hook: copies `bytes` bytes of the keypoint extraction's scratch plane (the candidate plane of
+ * kpe_main / kpe_finish; in builds with -DRMX_BS_STAMP the phase time stamps of kpe_bs's workgroups, eight
+ * 64-bit words each, tools/bs_stamps.py) to host memory.  Synchronises.  No counterpart in the reference. */
+int rmx_debug_kpe_scratch(rmx_ctx* ctx, void* host_dst, size_t bytes);
+
 #ifdef __cplusplus
 }
 #endif

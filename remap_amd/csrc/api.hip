@@ -42,8 +42,8 @@ struct rmx_ctx {
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
-  bool kpe_bs = false;         // 3x3 pass on bit planes (kpe_bs.hip): widths that are multiples of 16
-  uint32_t bs_ra = 24;         // rows per strip of kpe_bs (two strips per workgroup)
+  bool kpe_bs = false;         // 3x3 pass on bit planes (kpe_bs.hip): widths that are multiples of 16 (RMX_KPE_BS=0: kpe_mf)
+  uint32_t bs_ra = 12;         // rows per strip of kpe_bs (two strips per workgroup)
   // launch shape of kpe_fused for this context's frames (plan_fused); ok = false: kpe_main + kpe_finish
   struct FusedPlan {
     bool ok = false, v16 = false;
@@ -279,7 +279,8 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_SUB_MIB")) ctx->sub_mib = (uint32_t)std::max(1, atoi(e));
   if (const char* e = getenv("RMX_OVERLAP")) ctx->overlap_subs = (uint32_t)std::max(0, atoi(e));
   if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
-  if (const char* e = getenv("RMX_KPE_BS")) ctx->kpe_bs = atoi(e) != 0 && width % 16 == 0;
+  ctx->kpe_bs = width % 16 == 0;
+  if (const char* e = getenv("RMX_KPE_BS")) ctx->kpe_bs = ctx->kpe_bs && atoi(e) != 0;
   if (const char* e = getenv("RMX_BS_RA")) ctx->bs_ra = (uint32_t)std::min<int>(std::max(1, atoi(e)), (int)KPE_BS_RA_MAX);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
@@ -529,7 +530,9 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     }
     RMX_HIP(e);
   }
-  if (!ctx->fused.ok && ctx->kpe_bs) {
+  // the two-kernel form (RMX_KPE_PAIR) and the sub-batch experiments exist for kpe_main / kpe_finish only
+  const bool use_bs = !ctx->fused.ok && ctx->kpe_bs && !overlap && getenv("RMX_KPE_PAIR") == nullptr;
+  if (use_bs) {
     KpeParams p{};
     p.frames = frames;
     p.median = median;
@@ -548,6 +551,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     if (p.HB) p.groups = (n + p.HB - 1) / p.HB;
     p.rows_per_strip = std::max(6u, std::min(ctx->bs_ra, (ctx->H + 1) / 2) / 6 * 6);
     p.kmax = ctx->kmax;
+    p.cand = ctx->cand;  // (diagnostic builds only: phase stamps)
     dim3 grid((p.groups + 3) / 4, (ctx->H + 2 * p.rows_per_strip - 1) / (2 * p.rows_per_strip));
     {
       Timer t(ctx, &ctx->ms_kpe);
@@ -555,7 +559,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     }
     RMX_HIP(hipGetLastError());
   }
-  for (uint32_t f0 = 0; !ctx->fused.ok && !ctx->kpe_bs && f0 < n; f0 += sub, ++sub_idx) {
+  for (uint32_t f0 = 0; !ctx->fused.ok && !use_bs && f0 < n; f0 += sub, ++sub_idx) {
     const uint32_t m = std::min(sub, n - f0);
     KpeParams p{};
     p.frames = frames + (size_t)f0 * ctx->W * ctx->H;

@@ -24,7 +24,8 @@
 
 namespace rmx {
 
-constexpr uint32_t KPE_BS_RA_MAX = 32;  // rows per strip (a row-presence mask fits one word)
+constexpr uint32_t KPE_BS_RA_MAX = 30;  // rows per strip (a multiple of 6; row index: 5 bits of a list entry)
+constexpr uint32_t KPE_BS_LIST = 2048;   // candidates handed out per round
 
 constexpr uint64_t kBsRankTbl = bs::pack_tbl(kN2O, false);
 constexpr uint64_t kBsNativeOfInvRank = bs::pack_tbl(kO2N, true);
@@ -61,7 +62,7 @@ __device__ __forceinline__ void bs_make_row(const BsRaw& w, bs::Row& R) {
 }
 
 // The streaming pass of one workgroup: medians to HBM, candidate words to s_c[row step][thread].
-// f_out / c_out: the lane's frame and 16-pixel chunk (c_out = 0xffffffff: halo / idle lane or past the batch).
+// s_f / s_col [thread]: the lane's frame and 16-pixel chunk (0xffffffff: halo / idle lane or past the batch).
 //
 // Lanes.  p.HB = rows per wave (whole-row layout) or 0.  Whole rows: a wave holds HB complete image rows
 // (same y, consecutive frames: 3 x 20 chunks at 320 pixels, four lanes idle); what a row's first and last
@@ -79,16 +80,24 @@ __device__ __forceinline__ void bs_make_row(const BsRaw& w, bs::Row& R) {
 #ifndef RMX_BS_DEPTH
 #define RMX_BS_DEPTH 2  // row pairs in flight
 #endif
-__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t& f_out, uint32_t& c_out) {
-  const uint32_t lane = threadIdx.x & 63u;
-  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  f_out = 0;
-  c_out = 0xffffffffu;
-  // XCD-aware block remap (bijective): blocks that share an XCD get neighbouring groups.
+// XCD-aware block remap (bijective): blocks that share an XCD get neighbouring groups.
+__device__ __forceinline__ uint32_t bs_logical_block() {
   const uint32_t nb = gridDim.x, bid = blockIdx.x;
   const uint32_t bq = nb >> 3, br = nb & 7u, xcd = bid & 7u;
-  const uint32_t lb = (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (bid >> 3);
-  const uint32_t g = lb * 4 + wv;
+  return (xcd < br ? xcd * (bq + 1) : br * (bq + 1) + (xcd - br) * bq) + (bid >> 3);
+}
+// first frame of wave group g (the frames of a workgroup's four waves follow each other)
+__device__ __forceinline__ uint32_t bs_first_frame(const KpeParams& p, uint32_t g) {
+  if (p.HB) return g * p.HB;
+  const int64_t L0 = (int64_t)g * 62 - 1;
+  return (uint32_t)((L0 < 0 ? 0 : (uint64_t)L0) / p.Wd);
+}
+__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t* s_f, uint32_t* s_col) {
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  s_f[threadIdx.x] = 0;  // (written before the walk: nothing but the thread index lives across it)
+  s_col[threadIdx.x] = 0xffffffffu;
+  const uint32_t g = bs_logical_block() * 4 + wv;
   if (g >= p.groups) return;  // whole wave
 
   const uint32_t Wc = p.Wd;  // 16-byte chunks per row
@@ -118,8 +127,8 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
   const rsrc_t rout = make_rsrc(p.median + (size_t)f0 * frame_bytes, recs);
   const uint32_t voff_st = lane_ok ? voff : 0xffffffffu;  // dropped by the range check
   if (lane_ok) {
-    f_out = f;
-    c_out = c;
+    s_f[threadIdx.x] = f;
+    s_col[threadIdx.x] = c;
   }
   // processed x: [2, W-3] (kpe.hpp:183-184): the first two pixels of a row's first chunk and the last
   // two of its last chunk are not
@@ -216,6 +225,101 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 #undef RMX_BS_SELECT
 }
 
+// ---- finishing the candidates -----------------------------------------------------------------------------
+// compute_pixel's second half (kpe.hpp:316-321) asks two questions about p5 = median_pixel(H5, 12), the 12th
+// largest rank of the 5x5 window: is it p3 (then the pixel is no keypoint) and, for keypoints, is it p1 (the
+// weight).  Neither needs p5 itself: with C(t) = #(rank >= t), p5 == v  <=>  C(v) >= 12 > C(v + 1)
+// (kpe.hpp:326-340 returns the largest t whose count from the top reaches 12).  So every candidate gets two
+// counts (p3, p3 + 1) instead of kpe.hip's four-step search, and only the survivors (7-18 %) — queued per
+// wave and handled 64 at a time — get two more (p1, p1 + 1), their code bytes and the append.
+struct BsWin {
+  uint32_t w[5], e[5];  // natives: pixels x-2 .. x+1 of each row, and pixel x+2
+};
+__device__ __forceinline__ void bs_window(const CandData& d, uint32_t x, BsWin& W) {
+  const uint32_t s = (x - 2) & 3u;
+#pragma unroll
+  for (int r = 0; r < 5; ++r) {
+    const uint32_t lo = d.lo[r] & 0x0f0f0f0fu, hi = d.hi[r] & 0x0f0f0f0fu;
+    W.w[r] = __builtin_amdgcn_alignbyte(hi, lo, s);
+    W.e[r] = (hi >> (8 * s)) & 0xffu;
+  }
+}
+__device__ __forceinline__ uint32_t map_ord80(uint32_t w) {  // rank | 0x80 per byte
+  return map16<ord4(0) | 0x80808080u, ord4(4) | 0x80808080u, ord4(8) | 0x80808080u, ord4(12) | 0x80808080u>(w);
+}
+// ranks of the 25 pixels (bit 7 of every byte set; the three unused bytes of v[6] hold rank 0, which only a
+// threshold of 0 counts — and then the count is past 12 anyway)
+__device__ __forceinline__ void bs_ranks(const BsWin& W, uint32_t (&v)[7]) {
+#pragma unroll
+  for (int r = 0; r < 5; ++r) v[r] = map_ord80(W.w[r]);
+  v[5] = map_ord80(W.e[0] | W.e[1] << 8 | W.e[2] << 16 | W.e[3] << 24);
+  v[6] = map_ord80(W.e[4]);
+}
+// 128 * #(rank >= t), t in 0..16
+__device__ __forceinline__ uint32_t bs_count_ge(const uint32_t (&v)[7], uint32_t t) {
+  const uint32_t T = t * 0x01010101u;
+  uint32_t acc = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc = __builtin_amdgcn_sad_u8((v[i] - T) & 0x80808080u, 0u, acc);
+  return acc;
+}
+__device__ __forceinline__ bool bs_rank12_is(const uint32_t (&v)[7], uint32_t t) {
+  return bs_count_ge(v, t) >= 12u * 128u && bs_count_ge(v, t + 1) < 12u * 128u;
+}
+// 4th largest of the inner 3x3 (kpe.hpp:313-314) from the ranks of rows 1-3, with kpe.hip's network
+__device__ __forceinline__ uint32_t bs_p3(const uint32_t (&v)[7]) {
+  uint32_t lo[3], md[3], hi[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    const uint32_t q = v[r + 1];
+    sort3((q >> 8) & 0xffu, (q >> 16) & 0xffu, q >> 24, lo[r], md[r], hi[r]);
+  }
+  const uint32_t a = umax3(lo[0], lo[1], md[2]);
+  const uint32_t b = umed3(md[0], md[1], hi[2]);
+  const uint32_t c = umed3(hi[0], hi[1], lo[2]);
+  return umed3(a, b, c) & 0xfu;
+}
+// stage 1: is the candidate a keypoint?
+__device__ __forceinline__ bool bs_is_keypoint(uint32_t x, const CandData& d) {
+  BsWin W;
+  uint32_t v[7];
+  bs_window(d, x, W);
+  bs_ranks(W, v);
+  return !bs_rank12_is(v, bs_p3(v));
+}
+// stage 2: weight, code bytes (kpe.hpp:342-379), the record goes to row `slot` of the frame's raw table
+__device__ __forceinline__ void bs_emit_keypoint(const KpeParams& p, uint32_t x, uint32_t y, uint32_t f, bool kp, uint32_t slot,
+                                                 const CandData& d) {
+  BsWin W;
+  uint32_t v[7];
+  bs_window(d, x, W);
+  bs_ranks(W, v);
+  const uint32_t p1 = (v[2] >> 16) & 0xfu;
+  const uint32_t weight = bs_rank12_is(v, p1) ? 1u : 2u;
+  const uint32_t* w = W.w;
+  const uint32_t* e = W.e;
+  const uint32_t a0 = nib16(w[0]);
+  const uint32_t b2 = (w[1] & 0xfu) | (e[0] << 4);
+  const uint32_t a1 = nib16((w[1] >> 8) | (e[1] << 24));
+  const uint32_t a2 = nib16(w[2]);
+  const uint32_t b7 = (w[3] & 0xfu) | (e[2] << 4);
+  const uint32_t a3 = nib16((w[3] >> 8) | (e[3] << 24));
+  const uint32_t a4 = nib16(w[4]);
+  const uint32_t b12 = weight | (e[4] << 4);
+  if (kp) {
+    if (slot < p.kmax) {
+      RawDesc* dd = p.raw + (size_t)f * p.kmax + slot;
+      const uint4 c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);
+      const uint4 m4 = make_uint4(x | y << 16, 0u, 0u, 0u);
+      reinterpret_cast<uint4*>(dd)[0] = c4;
+      reinterpret_cast<uint4*>(dd)[1] = m4;
+    } else {
+      atomicOr(&p.status[0], 1u);
+    }
+  }
+}
+
+
 // LDS: s_c[ra][256] candidate words (dynamic), then the hand-out tables.
 #ifndef RMX_BS_WAVES
 #define RMX_BS_WAVES 4
@@ -223,35 +327,28 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   uint32_t(*s_c)[256] = reinterpret_cast<uint32_t(*)[256]>(s_dyn);
-  __shared__ uint32_t s_f[256], s_col[256], s_cum[256];
-  __shared__ uint32_t s_tbase[257];
+  __shared__ uint32_t s_f[256], s_col[256];
   __shared__ uint32_t s_scan[8];
+  __shared__ uint32_t s_list[KPE_BS_LIST];  // candidates of a round: thread | row << 8 | bit << 13
+  __shared__ uint32_t s_surv[KPE_BS_LIST];  // its keypoints: the same | place among its frame's keypoints of this round << 18
+  __shared__ uint32_t s_fcnt[256], s_fbase[256];  // per frame of the workgroup: keypoints of this round, their first table row
+  __shared__ uint32_t s_ns;
   const uint32_t tid = threadIdx.x;
   const uint32_t RA = p.rows_per_strip;
+#if defined(RMX_BS_STAMP)  /* diagnostic build (tools/bs_stamps.py): phase times of every workgroup, in p.cand */
+  uint64_t stamp[8];
+  uint32_t nstamp = 0;
+#define RMX_STAMP() stamp[nstamp++] = __builtin_amdgcn_s_memtime()
+#else
+#define RMX_STAMP()
+#endif
+  RMX_STAMP();
   for (uint32_t k = 0; k < RA; ++k) s_c[k][tid] = 0;
-  {
-    uint32_t f, c;
-#if defined(RMX_BS_PRIO)  /* experiment: the streaming phase ahead of other workgroups' finishing phase */
-    __builtin_amdgcn_s_setprio(1);
-#endif
-    kpe_bs_body(p, s_c, f, c);
-#if defined(RMX_BS_PRIO)
-    __builtin_amdgcn_s_setprio(0);
-#endif
-    s_f[tid] = f;
-    s_col[tid] = c;
-  }
-  // this thread's candidates, with the running counts after 8, 16 and 24 rows packed beside them
-  uint32_t cnt = 0, cum = 0;
-  for (uint32_t k = 0; k < RA; ++k) {
-    if (k == 8 || k == 16 || k == 24) cum |= cnt << (10 * (k / 8 - 1));
-    cnt += (uint32_t)__builtin_popcount(s_c[k][tid]);
-  }
-  if (RA <= 8) cum |= cnt;
-  if (RA <= 16) cum |= cnt << 10;
-  if (RA <= 24) cum |= cnt << 20;
-  s_cum[tid] = cum;
+  kpe_bs_body(p, s_c, s_f, s_col);
+  RMX_STAMP();  // 1: streamed
   const uint32_t lane = tid & 63u, wv = tid >> 6;
+  uint32_t cnt = 0;  // this thread's candidates
+  for (uint32_t k = 0; k < RA; ++k) cnt += (uint32_t)__builtin_popcount(s_c[k][tid]);
   uint32_t incl = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -259,7 +356,7 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
     if (lane >= (uint32_t)o) incl += t;
   }
   if (lane == 63) s_scan[wv] = incl;
-  __syncthreads();
+  __syncthreads();  // also: s_f, s_col and the candidate words of all threads
   uint32_t wbase = 0, total = 0;
   for (uint32_t k = 0; k < 4; ++k) {
     uint32_t sc = s_scan[k];
@@ -269,62 +366,121 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
 #if defined(RMX_BS_NOFIN)  /* ablation: the streaming pass alone */
   total = 0;
 #endif
-  s_tbase[tid] = wbase + incl - cnt;
-  if (tid == 0) s_tbase[256] = total;
-  __syncthreads();
+  const uint32_t my_base = wbase + incl - cnt;
   const uint32_t ya = blockIdx.y * 2 * RA;
-  auto locate = [&](uint32_t k, uint32_t& x, uint32_t& y, uint32_t& f) {
-    uint32_t lo = 0, hi = 256;  // owner thread: largest t with s_tbase[t] <= k
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (s_tbase[mid] <= k)
-        lo = mid;
-      else
-        hi = mid;
-    }
-    uint32_t nth = k - s_tbase[lo];
-    const uint32_t cm = s_cum[lo];
-    uint32_t kb = 0;  // the block of eight rows, then the row
-    if (nth >= ((cm >> 20) & 1023u))
-      kb = 24, nth -= (cm >> 20) & 1023u;
-    else if (nth >= ((cm >> 10) & 1023u))
-      kb = 16, nth -= (cm >> 10) & 1023u;
-    else if (nth >= (cm & 1023u))
-      kb = 8, nth -= cm & 1023u;
-    uint32_t w = s_c[kb][lo];
-    for (;;) {
-      uint32_t c = (uint32_t)__builtin_popcount(w);
-      if (nth < c) break;
-      nth -= c;
-      w = s_c[++kb][lo];
-    }
-    uint32_t b = 0;
-#pragma unroll
-    for (uint32_t sft = 16; sft >= 1; sft >>= 1) {
-      uint32_t lowc = (uint32_t)__builtin_popcount(w & ((1u << sft) - 1u));
-      if (nth >= lowc) {
-        nth -= lowc;
-        w >>= sft;
-        b += sft;
+  const uint32_t first_frame = bs_first_frame(p, bs_logical_block() * 4);
+  // Hand-out: every thread writes its own candidates (thread, row, bit) to a list in LDS at the places its
+  // prefix count assigns them; the list is then read densely.  (kpe.hip's hand-out searches the prefix
+  // counts for the owner of candidate k, then its words, then the bit: ~100 instructions per candidate
+  // against ~8 per candidate written and a handful to read it back.)  Workgroups with more candidates than
+  // the list holds go around again.
+  auto decode = [&](uint32_t e, uint32_t& x, uint32_t& y, uint32_t& f) {
+    const uint32_t t = e & 255u, kb = (e >> 8) & 31u, b = e >> 13;
+    x = s_col[t] * 16 + (b & 15u);
+    y = ya + (b >> 4) * RA + kb;
+    f = s_f[t];
+  };
+  // Table rows are reserved once per round and frame: every keypoint takes a place among its frame's keypoints
+  // with an LDS atomic, one lane per frame then adds the round's count to the frame's global counter (all
+  // frames of the workgroup in one instruction), and the records are written without further atomics.  (A
+  // returning global atomic per wave and frame in the resolve loop cost ~2 us of latency each, one after the
+  // other: the workgroup's finish, not its instruction count, was what the kernel waited for.)
+  const uint32_t fwg = first_frame;  // the workgroup's frames are [fwg, fwg + 256)
+  s_fcnt[tid] = 0;
+  if (tid == 0) s_ns = 0;
+  RMX_STAMP();  // 2: counted
+  for (uint32_t r0 = 0; r0 < total; r0 += KPE_BS_LIST) {  // uniform: barriers inside
+    __syncthreads();  // the previous round is done (first round: s_fcnt, s_ns)
+    if (my_base < r0 + KPE_BS_LIST && my_base + cnt > r0) {
+      uint32_t idx = my_base;
+      for (uint32_t k = 0; k < RA && idx < r0 + KPE_BS_LIST; ++k) {
+        uint32_t w = s_c[k][tid];
+        const uint32_t c = (uint32_t)__builtin_popcount(w);
+        if (idx + c <= r0) {
+          idx += c;
+          continue;
+        }
+        while (w) {
+          const uint32_t b = (uint32_t)__builtin_ctz(w);
+          w &= w - 1;
+          if (idx >= r0 && idx < r0 + KPE_BS_LIST) s_list[idx - r0] = tid | k << 8 | b << 13;
+          ++idx;
+        }
       }
     }
-    x = s_col[lo] * 16 + (b & 15u);
-    y = ya + (b >> 4) * RA + kb;
-    f = s_f[lo];
-  };
-  for (uint32_t k0 = 0; k0 < total; k0 += 512) {
-    const uint32_t ka = k0 + tid, kb = k0 + 256 + tid;
-    const bool act_a = ka < total, act_b = kb < total;
-    if (__builtin_amdgcn_ballot_w64(act_a) == 0) break;  // this wave's lanes are past the last candidate (no barriers below)
-    uint32_t xa = 2, ya2 = 2, fa = 0, xb = 2, yb2 = 2, fb = 0;
-    if (act_a) locate(ka, xa, ya2, fa);
-    if (act_b) locate(kb, xb, yb2, fb);
-    CandData da, db;
-    gather_candidate(p, xa, ya2, fa, da);
-    gather_candidate(p, xb, yb2, fb, db);
-    resolve_candidate<true>(p, xa, ya2, fa, act_a, da);
-    if (k0 + 256 < total) resolve_candidate<true>(p, xb, yb2, fb, act_b, db);
+    __syncthreads();
+    if (r0 == 0) RMX_STAMP();  // 3: listed
+    const uint32_t m = min(KPE_BS_LIST, total - r0);
+    // stage 1: two candidates per thread and pass, both gathers in flight before the first test
+    for (uint32_t k0 = 0; k0 < m; k0 += 512) {
+      if (k0 + (tid & ~63u) >= m) break;  // this wave's lanes are past the round's last candidate
+      uint32_t e[2], x[2], y[2], f[2];
+      CandData d[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t k = k0 + 256 * c + tid;
+        e[c] = k < m ? s_list[k] : 0xffffffffu;
+        x[c] = 2, y[c] = 2, f[c] = fwg;
+        if (e[c] != 0xffffffffu) decode(e[c], x[c], y[c], f[c]);
+        gather_candidate(p, x[c], y[c], f[c], d[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (k0 + 256 * c + (tid & ~63u) >= m) break;  // uniform
+        const bool kp = e[c] != 0xffffffffu && bs_is_keypoint(x[c], d[c]);
+        const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
+        if (km) {
+          uint32_t base = 0;
+          const uint32_t leader = (uint32_t)__builtin_amdgcn_readfirstlane((int)__builtin_ctzll(km));
+          if (lane == leader) base = atomicAdd(&s_ns, (uint32_t)__builtin_popcountll(km));
+          base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+          if (kp) s_surv[base + mbcnt(km)] = e[c] | atomicAdd(&s_fcnt[f[c] - fwg], 1u) << 18;
+        }
+      }
+    }
+    __syncthreads();
+    if (r0 == 0) RMX_STAMP();  // 4: tested
+    {  // one lane per frame: this round's rows
+      const uint32_t c = s_fcnt[tid];
+      if (c) {
+        s_fbase[tid] = atomicAdd(&p.kcount[fwg + tid], c);
+        s_fcnt[tid] = 0;
+      }
+    }
+    __syncthreads();
+    if (r0 == 0) RMX_STAMP();  // 5: rows reserved
+    const uint32_t ns = s_ns;
+    for (uint32_t k0 = 0; k0 < ns; k0 += 512) {
+      if (k0 + (tid & ~63u) >= ns) break;
+      uint32_t e[2], x[2], y[2], f[2];
+      CandData d[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const uint32_t k = k0 + 256 * c + tid;
+        e[c] = k < ns ? s_surv[k] : 0xffffffffu;
+        x[c] = 2, y[c] = 2, f[c] = fwg;
+        if (e[c] != 0xffffffffu) decode(e[c] & 0x3ffffu, x[c], y[c], f[c]);
+        gather_candidate(p, x[c], y[c], f[c], d[c]);
+      }
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (k0 + 256 * c + (tid & ~63u) >= ns) break;
+        const bool kp = e[c] != 0xffffffffu;
+        bs_emit_keypoint(p, x[c], y[c], f[c], kp, kp ? s_fbase[f[c] - fwg] + (e[c] >> 18) : 0u, d[c]);
+      }
+    }
+    __syncthreads();  // s_ns has been read by everyone
+    if (r0 == 0) RMX_STAMP();  // 6: emitted
+    if (tid == 0) s_ns = 0;
   }
+#if defined(RMX_BS_STAMP)
+  if (tid == 0) {
+    uint64_t* out = reinterpret_cast<uint64_t*>(p.cand) + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8;
+    for (uint32_t k = 0; k < 7; ++k) out[k] = k < nstamp ? stamp[k] : 0;
+    out[7] = total | (uint64_t)s_ns << 32;
+  }
+#endif
+#undef RMX_STAMP
 }
 
 }  // namespace rmx

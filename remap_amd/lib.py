@@ -35,6 +35,7 @@ SYMBOLS = [
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
     "rmx_debug_umap_order",
+    "rmx_debug_kpe_scratch",
 ]
 
 
@@ -102,6 +103,7 @@ def load():
     lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_resolve.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32)]
     lib.rmx_debug_umap_order.argtypes = [vp, vp, u32, vp]
+    lib.rmx_debug_kpe_scratch.argtypes = [vp, vp, C.c_size_t]
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
     lib.rmx_frc_scan_block.argtypes = [vp, vp, vp, u32, C.c_int, vp, vp, vp]

@@ -139,3 +139,43 @@ def test_ctx_create_rejects_bad_arguments_without_a_gpu():
     assert so.rmx_ctx_create(0, 320, 240, 4, 2, 16, 64, None, None) == -1
     assert so.rmx_kpe_batch(None, None, 0, None, None, None) == -1
     assert so.rmx_fgm_extent(None, 0, 320, 240, None, None, None, None) == -1
+
+
+def test_bitplane_3x3_pass_matches_oracle(tmp_path):
+    """remap_amd/csrc/bitslice.h (the arithmetic of kpe_bs.hip: bytes <-> bit planes, rank tables on
+    planes, the radix selection of the 4th largest of nine, candidate flags) compiled for the host and
+    run in the kernel's arrangement (tests/cpp/bitslice_check.cpp) against the oracle's kpe
+    (reference kpe.hpp:308-340): medians byte for byte, candidates = pixels whose median differs."""
+    import ctypes
+    import subprocess
+
+    import orclib as O
+    from remap_amd.synth import scroller_v1
+
+    so = tmp_path / "libbitslice_check.so"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", str(so),
+                           os.path.join(ROOT, "tests", "cpp", "bitslice_check.cpp")])
+    lib = ctypes.CDLL(str(so))
+    lib.bs_planes_roundtrip.argtypes = [ctypes.c_void_p] * 3
+    lib.bs_kpe_3x3.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    rng = np.random.default_rng(1)
+    for _ in range(50):
+        px = rng.integers(0, 16, 32, dtype=np.uint8)
+        out, pl = np.zeros(32, np.uint8), np.zeros(4, np.uint32)
+        lib.bs_planes_roundtrip(px.ctypes.data, out.ctypes.data, pl.ctypes.data)
+        assert (px == out).all()
+        for q in range(4):
+            assert int(pl[q]) == sum(int((px[i] >> q) & 1) << i for i in range(32))
+    frames, _ = scroller_v1(3, dens=40)
+    cases = [frames[0], frames[2], rng.integers(0, 16, (240, 320), dtype=np.uint8), rng.integers(0, 16, (48, 64), dtype=np.uint8),
+             rng.integers(0, 3, (64, 32), dtype=np.uint8) * 5, np.zeros((16, 16), np.uint8)]
+    for fr in cases:
+        fr = np.ascontiguousarray(fr)
+        Hh, Ww = fr.shape
+        med, cand = np.zeros((Hh, Ww), np.uint8), np.zeros((Hh, Ww), np.uint8)
+        assert lib.bs_kpe_3x3(fr.ctypes.data, Ww, Hh, med.ctypes.data, cand.ctypes.data) == 0
+        omed = O.orc_kpe(fr, 1, 1, 0)[0]
+        assert np.array_equal(med, omed)
+        inner = np.zeros((Hh, Ww), bool)
+        inner[2:Hh - 4, 2:Ww - 2] = True
+        assert np.array_equal(cand.astype(bool), (omed != fr) & inner)

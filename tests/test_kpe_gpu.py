@@ -9,6 +9,19 @@ from remap_amd.synth import scroller_v1, upscale2
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["bs", "bs-halo", "mf"])
+def kpe_path(request, monkeypatch):
+    """The extraction kernels a context may pick (read from the environment when it is created): kpe_bs
+    (3x3 pass on bit planes, widths that are multiples of 16; whole image rows per wave, or 62 chunks + 2
+    halo lanes with short strips) and kpe_mf (any width)."""
+    if request.param == "mf":
+        monkeypatch.setenv("RMX_KPE_BS", "0")
+    elif request.param == "bs-halo":
+        monkeypatch.setenv("RMX_BS_HALO", "1")
+        monkeypatch.setenv("RMX_BS_RA", "6")
+    return request.param
+
+
 def run_kpe(frames, grid=(4, 2), overlap=16, kmax=4096):
     import torch
 
@@ -35,19 +48,19 @@ def check_against_oracle(frames, grid=(4, 2), overlap=16, kmax=4096, idx=None):
 
 
 @pytest.mark.parametrize("dens", [200, 40])
-def test_kpe_scroller_320x240(gpu, dens):
+def test_kpe_scroller_320x240(gpu, dens, kpe_path):
     frames, _ = scroller_v1(24, dens=dens)
     check_against_oracle(frames)
 
 
-def test_kpe_random_noise(gpu):
+def test_kpe_random_noise(gpu, kpe_path):
     # every pixel a candidate: stresses the queue, the 5x5 path and large K
     rng = np.random.default_rng(3)
     frames = rng.integers(0, 16, size=(3, 64, 128), dtype=np.uint8)
     check_against_oracle(frames, kmax=16384)
 
 
-def test_kpe_flat_and_edges(gpu):
+def test_kpe_flat_and_edges(gpu, kpe_path):
     frames = np.zeros((4, 48, 160), np.uint8)
     frames[1] = 7
     frames[2, :, 80:] = 9           # vertical edge
@@ -66,7 +79,7 @@ def test_kpe_ragged_width_and_single_region(gpu):
         check_against_oracle(np.ascontiguousarray(frames), grid=(1, 1), overlap=0)
 
 
-def test_kpe_640x480_upscaled(gpu):
+def test_kpe_640x480_upscaled(gpu, kpe_path):
     frames, _ = scroller_v1(4, dens=100)
     check_against_oracle(upscale2(frames), idx=[0, 3])
 
@@ -83,7 +96,7 @@ def test_kpe_kmax_overflow_is_reported(gpu):
     ctx.close()
 
 
-def test_kpe_many_frames_matches_single(gpu):
+def test_kpe_many_frames_matches_single(gpu, kpe_path):
     # batch result == per-frame result (frames packed across waves must not interact)
     frames, _ = scroller_v1(40, dens=60)
     med, tabs = run_kpe(frames)
@@ -105,7 +118,7 @@ def test_kpe_widths_not_multiple_of_four(gpu):
         check_against_oracle(frames, grid=grid, overlap=ov, kmax=16384)
 
 
-def test_kpe_large_frame_sort_path_kmax_16384(gpu):
+def test_kpe_large_frame_sort_path_kmax_16384(gpu, kpe_path):
     """A frame above 524 288 pixels has no rank bitmap: kpe_table_rest sorts 64-bit keys in LDS,
     128 KB of dynamic LDS at kmax = 16 384 (the default of kpe::extractor in the drop-in layer)
     — needs the launch attribute; more than 8 192 keypoints so the sort really is that wide."""
@@ -149,3 +162,39 @@ def test_kpe_tables_beyond_16384_rows(gpu):
     check_against_oracle(img, grid=(1, 1), overlap=0, kmax=1 << 17)
     two = np.ascontiguousarray(np.stack([img[0], np.roll(img[0], 5, axis=1)]))
     check_against_oracle(two, grid=(1, 1), overlap=0, kmax=1 << 17)
+
+
+def test_kpe_bs_shapes(gpu, kpe_path):
+    """Widths that are multiples of 16 in every lane layout of kpe_bs (whole rows per wave: 16 ... 64 chunks
+    dividing 64 with few lanes idle; otherwise 62 chunks + halo lanes), heights that are not multiples of
+    the strip pairs, single rows of chunks, batches that are not multiples of the rows per wave — and a
+    noise frame whose candidates need several rounds of the hand-out list."""
+    rng = np.random.default_rng(41)
+    for (H, W, grid, ov, n) in [(37, 16, (1, 1), 0, 5), (50, 32, (1, 1), 0, 7), (61, 64, (1, 1), 0, 4), (48, 160, (4, 2), 16, 5),
+                                (45, 336, (4, 2), 16, 4), (70, 512, (4, 2), 16, 3), (66, 1040, (4, 2), 16, 2), (240, 320, (4, 2), 16, 7)]:
+        base = rng.integers(0, 16, size=(n, H // 4 + 1, W // 4 + 1), dtype=np.uint8)
+        frames = np.ascontiguousarray(np.kron(base, np.ones((1, 4, 4), np.uint8))[:, :H, :W])
+        frames[n - 1] = rng.integers(0, 16, size=(H, W), dtype=np.uint8)  # noise: every pixel a candidate
+        check_against_oracle(frames, grid=grid, overlap=ov, kmax=1 << 17)
+
+
+def test_kpe_paths_agree_on_a_long_batch(gpu, monkeypatch):
+    """kpe_bs and kpe_mf on 3 001 frames: medians, counts and tables byte for byte (the batch is not a
+    multiple of the three rows a wave holds; dense frames so every workgroup hands out > 2 048 candidates)"""
+    import torch
+
+    frames, _ = scroller_v1(3001, dens=40)
+    d = torch.from_numpy(frames).cuda()
+    res = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RMX_KPE_BS", mode)
+        ctx = L.Context(320, 240, kmax=4096)
+        med, desc, kc = ctx.kpe(d)
+        assert ctx.kpe_status()[0] == 0
+        res.append((med.clone(), desc.clone(), kc.clone()))
+        ctx.close()
+    assert torch.equal(res[0][0], res[1][0]), "medians differ between kpe_bs and kpe_mf"
+    assert torch.equal(res[0][2], res[1][2]), "keypoint counts differ"
+    k = res[0][2].cpu().numpy()
+    a, b = res[0][1].cpu().numpy(), res[1][1].cpu().numpy()
+    assert all(a[i, : k[i]].tobytes() == b[i, : k[i]].tobytes() for i in range(len(k))), "tables differ"

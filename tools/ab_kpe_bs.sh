@@ -3,7 +3,7 @@
 # usage: tools/ab_kpe_bs.sh build   (here, no GPU)   |   tools/ab_kpe_bs.sh run [n] [dens]   (GPU box)
 set -e
 cd "$(dirname "$0")/.."
-variants=("base:" "d3:-DRMX_BS_DEPTH=3" "nofin:-DRMX_BS_NOFIN" "d3nofin:-DRMX_BS_DEPTH=3 -DRMX_BS_NOFIN" "copy:-DRMX_BS_COPY -DRMX_BS_NOFIN" "prio:-DRMX_BS_PRIO")
+variants=(${VARIANTS:-"base:" "d3:-DRMX_BS_DEPTH=3" "nofin:-DRMX_BS_NOFIN" "copy:-DRMX_BS_COPY -DRMX_BS_NOFIN"})
 if [ "$1" = build ]; then
   mkdir -p ab
   for v in "${variants[@]}"; do
@@ -19,6 +19,7 @@ else
       name=${v%%:*}
       for ra in ${RAS:-24 12}; do
         echo "== $name ra=$ra"
+        [ -f ab/bs_$name.so ] || continue
         RMX_SO=$PWD/ab/bs_$name.so RMX_KPE_BS=1 RMX_BS_RA=$ra python3 tools/perf_kpe.py $n $dens | grep -m1 -A1 "launches" | tail -1
       done
     done
