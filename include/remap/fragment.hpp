@@ -106,6 +106,45 @@ public:
     zero_ = {0, 0};
   }
 
+  // fgm.hpp:145-153,235-295 — the empty border of the canvas: left_ / right_ = the fewest empty dots before
+  // the first / after the last non-empty dot of any row, top_ / bottom_ the same per column; a side keeps
+  // the canvas width (height) if no row (column) has a dot.  "Non-empty" is the mask rmx_fgm_blend
+  // computes (any bin != 0), so one byte per dot comes to the host instead of thirty-two.
+  mrl::region_t margins() const {
+    const std::size_t w = dim_.width_, h = dim_.height_;
+    mrl::region_t region{w, h, w, h};
+    if (!canvas_) return region;
+    rmx_ctx* c = any_ctx();
+    remap::device_buffer img{c, dim_.area()}, msk{c, dim_.area()};
+    remap::check(rmx_fgm_blend(c, canvas_.get<std::uint16_t>(), std::uint32_t(w), std::uint32_t(h), img.get<std::uint8_t>(),
+                               msk.get<std::uint8_t>()),
+                 c, "rmx_fgm_blend");
+    std::vector<std::uint8_t> mask(dim_.area());
+    remap::check(rmx_download(c, mask.data(), msk.get(), mask.size()), c, "rmx_download");
+    std::vector<std::size_t> first_y(w, h), last_y(w, h);  // per column: first / last non-empty row (h: none)
+    for (std::size_t y = 0; y < h; ++y) {
+      std::uint8_t const* row = mask.data() + y * w;
+      std::size_t lo = w, hi = w;
+      for (std::size_t x = 0; x < w; ++x)
+        if (row[x]) {
+          if (lo == w) lo = x;
+          hi = x;
+          if (first_y[x] == h) first_y[x] = y;
+          last_y[x] = y;
+        }
+      if (lo != w) {
+        region.left_ = std::min(region.left_, lo);
+        region.right_ = std::min(region.right_, w - 1 - hi);
+      }
+    }
+    for (std::size_t x = 0; x < w; ++x)
+      if (first_y[x] != h) {
+        region.top_ = std::min(region.top_, first_y[x]);
+        region.bottom_ = std::min(region.bottom_, h - 1 - last_y[x]);
+      }
+    return region;
+  }
+
   // canvas as a host matrix (downloads; an untouched fragment is all zero)
   matrix_type dots() const {
     matrix_type m{dim_};

@@ -12,9 +12,13 @@
 #pragma once
 
 #include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
 #include <filesystem>
 #include <fstream>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "fragment.hpp"
@@ -25,10 +29,6 @@ namespace details {
 template <typename T>
 void put(std::ostream& o, T const& v) {
   o.write(reinterpret_cast<char const*>(&v), sizeof(T));
-}
-template <typename T>
-void get(std::istream& i, T& v) {
-  i.read(reinterpret_cast<char*>(&v), sizeof(T));
 }
 }  // namespace details
 
@@ -54,40 +54,93 @@ void write(std::filesystem::path dir, Iter first, Iter last) {
   }
 }
 
-[[nodiscard]] inline std::vector<fgm::fragment> read(std::filesystem::path dir) {
-  std::vector<std::filesystem::path> files;
-  std::copy(std::filesystem::directory_iterator(dir), std::filesystem::directory_iterator(), std::back_inserter(files));
-  std::sort(files.begin(), files.end(),
-            [](auto& a, auto& b) { return std::stoi(a.filename().string()) < std::stoi(b.filename().string()); });
-  std::vector<fgm::fragment> result;
-  for (auto& file : files) {
-    std::ifstream input{file, std::ios::in | std::ios::binary};
-    mrl::dimensions_t dim{};
-    details::get(input, dim);
-    fgm::fragment::matrix_type temp{dim};
-    input.read(reinterpret_cast<char*>(temp.data()), std::streamsize(dim.area() * sizeof(fgm::dot_type)));
-    fgm::point_t zero{};
-    details::get(input, zero);
-    std::size_t count{};
-    details::get(input, count);
-    std::vector<fgm::frame> frames{};
-    for (std::size_t i = 0; i < count; ++i) {
-      fgm::frame frame{};
-      details::get(input, frame.number_);
-      details::get(input, frame.position_);
-      std::size_t size_i{};
-      details::get(input, size_i);
-      frame.data_.image_.resize(size_i);
-      input.read(reinterpret_cast<char*>(frame.data_.image_.data()), std::streamsize(size_i));
-      std::size_t size_m{};
-      details::get(input, size_m);
-      frame.data_.median_.resize(size_m);
-      input.read(reinterpret_cast<char*>(frame.data_.median_.data()), std::streamsize(size_m));
-      frames.push_back(std::move(frame));
-    }
-    result.emplace_back(std::move(temp), mrl::dimensions_t{1, 1}, zero, std::move(frames));
+namespace details {
+// A fragment file held in memory, consumed front to back.  Every take() is bounds-checked: a truncated
+// or foreign file ends the parse (ok() turns false) instead of reading past the buffer — the reference
+// streams field by field and trusts the file.
+class cursor {
+public:
+  explicit cursor(std::filesystem::path const& file) {
+    std::ifstream in{file, std::ios::binary | std::ios::ate};
+    if (!in) return;
+    bytes_.resize(static_cast<std::size_t>(in.tellg()));
+    in.seekg(0);
+    in.read(bytes_.data(), std::streamsize(bytes_.size()));
+    good_ = static_cast<bool>(in);
   }
-  return result;
+  [[nodiscard]] bool ok() const noexcept { return good_; }
+  template <typename T>
+  [[nodiscard]] T take() {
+    T v{};
+    take_into(&v, sizeof(T));
+    return v;
+  }
+  void take_into(void* dst, std::size_t n) {
+    if (!good_ || n > bytes_.size() - at_) {
+      good_ = false;
+      return;
+    }
+    std::memcpy(dst, bytes_.data() + at_, n);
+    at_ += n;
+  }
+  [[nodiscard]] icd::compressed_t blob() {  // u64 size + bytes
+    auto const n = take<std::uint64_t>();
+    icd::compressed_t b;
+    if (good_ && n <= bytes_.size() - at_) {
+      b.resize(static_cast<std::size_t>(n));
+      take_into(b.data(), b.size());
+    } else {
+      good_ = false;
+    }
+    return b;
+  }
+
+private:
+  std::vector<char> bytes_;
+  std::size_t at_{0};
+  bool good_{false};
+};
+
+[[nodiscard]] inline bool parse_fragment(cursor& c, std::vector<fgm::fragment>& out) {
+  auto const dim = c.take<mrl::dimensions_t>();
+  if (!c.ok() || dim.area() == 0) return false;
+  fgm::fragment::matrix_type dots{dim};
+  c.take_into(dots.data(), dim.area() * sizeof(fgm::dot_type));
+  auto const zero = c.take<fgm::point_t>();
+  auto const count = c.take<std::uint64_t>();
+  std::vector<fgm::frame> frames;
+  for (std::uint64_t i = 0; c.ok() && i < count; ++i) {
+    fgm::frame f{};
+    f.number_ = c.take<decltype(f.number_)>();
+    f.position_ = c.take<fgm::point_t>();
+    f.data_.image_ = c.blob();
+    f.data_.median_ = c.blob();
+    frames.push_back(std::move(f));
+  }
+  if (!c.ok()) return false;
+  out.emplace_back(std::move(dots), mrl::dimensions_t{1, 1}, zero, std::move(frames));  // step (1, 1): ful.hpp:97-98
+  return true;
+}
+}  // namespace details
+
+// Fragments of `dir` in the order of their integer file names (the index write() gave them); entries
+// whose name is not a number are skipped, a file that does not parse ends the list there.
+[[nodiscard]] inline std::vector<fgm::fragment> read(std::filesystem::path dir) {
+  std::vector<std::pair<long, std::filesystem::path>> numbered;
+  for (auto const& entry : std::filesystem::directory_iterator(dir)) {
+    auto const name = entry.path().filename().string();
+    char* end = nullptr;
+    long const index = std::strtol(name.c_str(), &end, 10);
+    if (end != name.c_str() && *end == '\0') numbered.emplace_back(index, entry.path());
+  }
+  std::sort(numbered.begin(), numbered.end());
+  std::vector<fgm::fragment> fragments;
+  fragments.reserve(numbered.size());
+  for (auto const& [index, file] : numbered) {
+    details::cursor c{file};
+    if (!details::parse_fragment(c, fragments)) break;
+  }
+  return fragments;
 }
 
 }  // namespace ful

@@ -136,7 +136,10 @@ int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint
 /* Synchronises; returns RMX_ERR_CAPACITY if a matcher workspace limit (groups per frame,
  * shared codes or distinct offsets per region pair) was exceeded since the last call —
  * the affected results are then invalid.  *flags (may be NULL) receives the limit bits:
- * 128 alone = only tickets that rmx_kpm_resolve can still compute are missing. */
+ * 128 alone = only tickets that rmx_kpm_resolve can still compute are missing;
+ * RMX_KPM_REMOTE_FAILURE (after rmx_frc_finish on a sharded stream) = some rank's block overflowed a
+ * table or hit a matcher limit that cannot be resolved: every rank must give the step up. */
+#define RMX_KPM_REMOTE_FAILURE 0x8000u
 int rmx_kpm_status(rmx_ctx* ctx, uint32_t* flags);
 
 /* The tickets rmx_kpm_seq left to the global-memory instance of the matcher: a region of a frame
@@ -183,6 +186,7 @@ int rmx_frc_scan(rmx_ctx* ctx, const int32_t* dxdy, const uint8_t* matched, uint
  *   rmx_frc_finish       synchronises once; *nfrag = fragments of the whole stream.
  * With ONE rank rmx_frc_apply_blocks may be left out: a block that is the whole stream is already in
  * place, and rmx_frc_scan_block leaves its fragment count for rmx_frc_finish.
+ * Bit 2 of summary[0] tells the other ranks that this block failed for good (RMX_KPM_REMOTE_FAILURE above).
  * Bit 1 of summary[0] tells the other ranks that this block has tickets left to rmx_kpm_resolve:
  * after rmx_frc_finish, rmx_kpm_status reports flag 128 on EVERY rank if it does on one, so the
  * ranks resolve (a no-op where nothing is left) and scan again together. */

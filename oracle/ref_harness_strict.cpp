@@ -218,6 +218,15 @@ void* ref_ful_read(const char* dir, uint32_t* n) {
 void* ref_ful_get(void* vec, uint32_t i) { return &(*static_cast<std::vector<fgm::fragment>*>(vec))[i]; }
 void ref_ful_free(void* vec) { delete static_cast<std::vector<fgm::fragment>*>(vec); }
 
+// fragment::margins (fgm.hpp:145-153,235-295): {left, top, right, bottom}
+void ref_frag_margins(void* f, uint64_t out[4]) {
+  auto r = static_cast<fgm::fragment*>(f)->margins();
+  out[0] = r.left_;
+  out[1] = r.top_;
+  out[2] = r.right_;
+  out[3] = r.bottom_;
+}
+
 void ref_frag_blend(void* f, uint8_t* image, uint8_t* mask) {
   auto b = static_cast<fgm::fragment*>(f)->blend();
   for (std::size_t i = 0; i < b.image_.size(); ++i) {

@@ -41,6 +41,7 @@ struct rmx_ctx {
   uint32_t* tab_ws = nullptr;  // kpe_table_big (kmax > 16 384): 2 * ceil(W*H/32) dwords per frame
   uint32_t n_cap = 0;
   uint32_t n_last = 0;       // frames of the last rmx_kpe_batch
+  size_t lds_table_rest = 64 * 1024, lds_fused = 64 * 1024;  // dynamic LDS granted to kpe_table_rest / kpe_fused on this context's device
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   bool kpe_bs = false;         // 3x3 pass on bit planes (kpe_bs.hip): widths that are multiples of 16 (RMX_KPE_BS=0: kpe_mf)
   uint32_t bs_ra = 12;         // rows per strip of kpe_bs (two strips per workgroup)
@@ -152,12 +153,11 @@ rmx_ctx::FusedPlan plan_fused(uint32_t W, uint32_t H) {
 }
 
 template <int R, bool V16>
-hipError_t launch_fused(const rmx_ctx::FusedPlan& pl, const KpeFusedParams& kp, hipStream_t stream) {
-  static uint32_t lds_set = 0;  // dynamic LDS above the 64-KB default needs the attribute once per size
-  if (pl.lds > 64 * 1024 && pl.lds > lds_set) {
+hipError_t launch_fused(const rmx_ctx::FusedPlan& pl, const KpeFusedParams& kp, hipStream_t stream, size_t& lds_granted) {
+  if (pl.lds > lds_granted) {  // dynamic LDS above the 64-KB default needs the attribute (per device: kept per context)
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&kpe_fused<R, V16>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds);
     if (e != hipSuccess) return e;
-    lds_set = pl.lds;
+    lds_granted = pl.lds;
   }
   const uint32_t groups = (kp.n + pl.fpb - 1) / pl.fpb;
   hipLaunchKernelGGL((kpe_fused<R, V16>), dim3(groups * kp.strips), dim3(pl.nt), pl.lds, stream, kp);
@@ -482,7 +482,8 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   std::swap(ctx->kraw, ctx->kraw_other);
   if (ctx->kraw_clean < n)
     RMX_HIP(hipMemsetAsync(ctx->kraw + ctx->kraw_clean, 0, (size_t)(n - ctx->kraw_clean) * sizeof(uint32_t), ctx->stream));
-  ctx->kraw_clean = n;  // (of the other buffer, once this batch's table kernels have run)
+  const uint32_t clean_after = n;  // (of the other buffer, once this batch's table kernels have been launched)
+  ctx->kraw_clean = 0;             // until then: an early error return must not leave it marked clean
   // Optional sub-batching (RMX_SUB_MIB): keeping frames + medians + candidate plane inside
   // the 256 MiB Infinity Cache between the streaming and the finishing pass was measured
   // SLOWER at every size (small launches cost more than the re-reads), so the default is
@@ -522,11 +523,11 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     {
       Timer t(ctx, &ctx->ms_kpe);
       if (pl.R == 8)
-        e = pl.v16 ? launch_fused<8, true>(pl, kp, ctx->stream) : launch_fused<8, false>(pl, kp, ctx->stream);
+        e = pl.v16 ? launch_fused<8, true>(pl, kp, ctx->stream, ctx->lds_fused) : launch_fused<8, false>(pl, kp, ctx->stream, ctx->lds_fused);
       else if (pl.R == 24)
-        e = pl.v16 ? launch_fused<24, true>(pl, kp, ctx->stream) : launch_fused<24, false>(pl, kp, ctx->stream);
+        e = pl.v16 ? launch_fused<24, true>(pl, kp, ctx->stream, ctx->lds_fused) : launch_fused<24, false>(pl, kp, ctx->stream, ctx->lds_fused);
       else
-        e = pl.v16 ? launch_fused<16, true>(pl, kp, ctx->stream) : launch_fused<16, false>(pl, kp, ctx->stream);
+        e = pl.v16 ? launch_fused<16, true>(pl, kp, ctx->stream, ctx->lds_fused) : launch_fused<16, false>(pl, kp, ctx->stream, ctx->lds_fused);
     }
     RMX_HIP(e);
   }
@@ -645,14 +646,15 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     hipLaunchKernelGGL(kpe_table, dim3((n + 3) / 4), dim3(256), 0, ctx->stream, tp);
     // frames too big for the rank bitmap sort 64-bit keys in LDS: 128 KB at kmax = 16 384, above
     // the 64 KB a launch gets without the attribute
-    static size_t lds_allowed = 64 * 1024;
-    if (lds > lds_allowed) {
+    // (the attribute belongs to the device the context runs on: remembered per context, not per process)
+    if (lds > ctx->lds_table_rest) {
       RMX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&kpe_table_rest), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-      lds_allowed = lds;
+      ctx->lds_table_rest = lds;
     }
     hipLaunchKernelGGL(kpe_table_rest, dim3(std::min(n, 4096u)), dim3(256), lds, ctx->stream, tp);
   }
   RMX_HIP(hipGetLastError());
+  ctx->kraw_clean = clean_after;
   return RMX_OK;
 }
 

@@ -121,7 +121,14 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
     p.carry[1] = s_carry.y;
     p.carry[2] = s_carry.c;
     if (p.summary) {
-      const int32_t pending = (p.kpm_status && (*p.kpm_status & 128u)) ? 2 : 0;
+      // bit 1: tickets left to rmx_kpm_resolve; bit 2: this block failed for good (a table overflowed in
+      // rmx_kpe_batch, status word 0, or the matcher hit a limit other than "tickets left") — so that every
+      // rank of a sharded stream takes the same branch after the exchange
+      int32_t pending = 0;
+      if (p.kpm_status) {
+        const uint32_t km = *p.kpm_status, ke = *(p.kpm_status - 1);
+        pending = ((km & 128u) ? 2 : 0) | ((ke || (km & ~128u)) ? 4 : 0);
+      }
       p.summary[0] = ((p.first_is_start || s_carry.c > 0) ? 1 : 0) | pending;
       p.summary[1] = s_carry.x;
       p.summary[2] = s_carry.y;
@@ -143,7 +150,7 @@ struct ApplyParams {
   const int32_t* summaries;  // world x 4
   int32_t* pos;
   uint32_t* frag;
-  uint32_t* nfrag_out;  // fragments of the whole stream; [1]: some block has tickets left to rmx_kpm_resolve
+  uint32_t* nfrag_out;  // fragments of the whole stream; [1]: bit 1 some block has tickets left to rmx_kpm_resolve, bit 2 some block failed
   uint32_t n, rank, world;
 };
 __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
@@ -152,7 +159,7 @@ __global__ __launch_bounds__(256) void frc_apply(ApplyParams p) {
   for (uint32_t q = 0; q < p.world; ++q) {  // (world is small; every thread folds for itself)
     const int32_t r = p.summaries[4 * q] & 1, x = p.summaries[4 * q + 1], y = p.summaries[4 * q + 2];
     const uint32_t c = (uint32_t)p.summaries[4 * q + 3];
-    pending |= (uint32_t)p.summaries[4 * q] & 2u;
+    pending |= (uint32_t)p.summaries[4 * q] & 6u;
     if (q < p.rank) {
       ax = r ? x : ax + x;
       ay = r ? y : ay + y;

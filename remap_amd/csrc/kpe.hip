@@ -14,14 +14,18 @@
 //     rows that see it; three sorted triples A,B,C are merged with
 //         med3( max3(A.lo,B.lo,C.md), med3(A.md,B.md,C.hi), med3(A.hi,B.hi,C.lo) )
 //     which equals the 4th largest of the nine (exhaustively verified over the 0/1
-//     principle, tests/test_rank_network.py) — 7 VALU ops per pixel;
+//     principle, tests/test_host_logic.py) — 7 VALU ops per pixel;
 //   * pixels whose centre differs from that value (1-8 % on the synthetic streams) are
-//     flagged in a 1-bit-per-pixel candidate plane; a second kernel (kpe_finish) hands the
-//     set bits out densely, 256 at a time: the 5x5 window is gathered from L2 / Infinity
-//     Cache, the 12th-largest-of-25 (median_pixel(H5, 12)) is found by a 4-step binary
-//     search with SWAR byte compares + v_sad_u8 counting, and keypoints are encoded and
-//     appended.  Keeping this divergent, latency-bound work out of the streaming kernel
-//     lets kpe_main run at 8 waves/SIMD with nothing but one load and one store per row.
+//     candidates.  The shipped kernel, kpe_mf, keeps a workgroup's candidate flags in LDS (one word per
+//     lane and 8 rows) and, after its walk, hands the set bits out densely: the 5x5 window is gathered
+//     from L2 / Infinity Cache (the workgroup has just streamed those lines), the 12th-largest-of-25
+//     (median_pixel(H5, 12)) is found by a 4-step binary search with SWAR byte compares + v_sad_u8
+//     counting, and keypoints are encoded and appended.  kpe_main + kpe_finish are the same two halves as
+//     separate launches with a 1-bit-per-pixel candidate plane in HBM between them (RMX_KPE_PAIR: the form
+//     of rounds 1-2a, kept for A/B timings).
+//
+// Since round 3 this file serves frame widths that are NOT multiples of 16; the others go through
+// kpe_bs.hip (3x3 pass on bit planes), which reuses gather_candidate from here.
 //
 // Work decomposition: a lane owns one dword (4 pixels) of a row and walks down a strip of
 // rows keeping three rows of sorted triples in registers; horizontally adjacent pixels
@@ -30,8 +34,8 @@
 // so waves stay full for any frame width; pixels whose window would cross a frame edge
 // are exactly the border pixels the reference never processes.
 //
-// HBM traffic of kpe_main: every frame byte is read once (+3 % halo re-reads served by L2),
-// every median byte written once, plus 1 bit per pixel of candidate plane (+6 %).
+// HBM traffic of the streaming half: every frame byte is read once (+3 % halo re-reads served by L2),
+// every median byte written once; kpe_main adds 1 bit per pixel of candidate plane (+6 %).
 #include "common.h"
 
 namespace rmx {

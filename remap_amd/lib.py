@@ -24,6 +24,7 @@ DESC_BYTES = 18
 
 RMX_OK = 0
 RMX_ERR_ARG, RMX_ERR_DEVICE, RMX_ERR_KMAX, RMX_ERR_CAPACITY, RMX_ERR_NOGPU = -1, -2, -3, -4, -5
+RMX_KPM_REMOTE_FAILURE = 0x8000  # rmx_kpm_status flag after rmx_frc_finish: some rank's block failed for good
 STATUS = {0: "RMX_OK", -1: "RMX_ERR_ARG", -2: "RMX_ERR_DEVICE", -3: "RMX_ERR_KMAX", -4: "RMX_ERR_CAPACITY",
           -5: "RMX_ERR_NOGPU"}
 

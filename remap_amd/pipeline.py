@@ -158,6 +158,8 @@ class Aligner:
         self.world = self.dist.get_world_size(group) if self.dist else 1
         self._bufs = {}
         self.blit_gate = None
+        self._deferred = None   # (out, halo) of a deferred step whose status has not been looked at yet
+        self._last_nfrag = None
 
     def _buf(self, name, shape, dtype):
         t = self.torch
@@ -187,6 +189,7 @@ class Aligner:
         deferred steps overflowed a table or a matcher limit (the status words are sticky)."""
         t = self.torch
         ctx = self.ctx
+        self._settle()  # a deferred step of this Aligner: its buffers and work lists are about to be reused
         n = frames.shape[0]
         if n_total is None:
             n_total = n * self.world
@@ -225,31 +228,16 @@ class Aligner:
                    lo=lo, hi=hi, nfrag=nfrag, n_total=n_total)
         if defer:
             assert not blit, "canvases need the positions on the host: not with defer=True"
-            check = False
+            assert check, "a deferred step is checked when it is settled"
+            # settled (status words, tickets left to rmx_kpm_resolve) before this Aligner's next step
+            # reuses the buffers and the matcher's work list, or in finish()
+            self._deferred = (out, halo)
+            if compress:
+                out["nic_image"] = ctx.nic_compress(frames.reshape(n, -1), pack=False)
+                out["nic_median"] = ctx.nic_compress(median.reshape(n, -1), pack=False)
+            return out
         if check:
-            rc, _ = ctx.kpe_status(want_max=False)
-            if rc:
-                _, maxk = ctx.kpe_status()
-                raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
-            rc, fl = ctx.kpm_status()
-            if rc == L.RMX_ERR_CAPACITY and fl == 128:
-                # regions / pairs the LDS matcher left to its global-memory instance (a frame with
-                # thousands of keypoints in one region): tickets computed there, offsets rewritten,
-                # positions derived again.  On a sharded stream every rank gets here if one does
-                # (the flag travels with the scan summaries), so the collectives below pair up.
-                ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
-                if self.world == 1:
-                    pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
-                    nfrag = carry[1] + 1
-                else:
-                    pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
-                    summ = _all_gather_flat(mine, self.world, self.dist, self.group)
-                    ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
-                    nfrag = ctx.frc_finish()
-                    ctx.kpm_status()  # (the flag of the first pass, gathered again)
-                out.update(pos=pos, frag=frag, nfrag=nfrag)
-            elif rc:
-                raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
+            self._check_step(out, halo)
         if compress:
             out["nic_image"] = ctx.nic_compress(frames.reshape(n, -1), pack=False)
             out["nic_median"] = ctx.nic_compress(median.reshape(n, -1), pack=False)
@@ -260,19 +248,59 @@ class Aligner:
             out["canvases"] = self.blit(frames, out["pos_all"], out["frag_all"], lo, hi)
         return out
 
-    def finish(self):
-        """Wait for the deferred steps: fragment count of the last one; raises if any of them
-        reported an overflow (rmx_kpe_status / rmx_kpm_status)."""
+    def _check_step(self, out, halo):
+        """Status words of the step that produced `out` (the stream has been waited for: rmx_frc_scan or
+        rmx_frc_finish cached them).  Raises on an overflow — on EVERY rank of a sharded stream if one rank
+        has one (the failure bit travels with the scan summaries), so that no rank is left alone in a
+        collective; runs the matcher's global-memory instance for tickets the LDS instances left
+        (rmx_kpm_resolve) and derives the positions again, all ranks together."""
         ctx = self.ctx
-        nfrag = ctx.frc_finish()
         rc, _ = ctx.kpe_status(want_max=False)
+        kpe_err = None
         if rc:
             _, maxk = ctx.kpe_status()
-            raise L.RemapError(rc, "rmx_kpe_status", f"a frame has {maxk} keypoints > kmax={self.kmax}")
+            kpe_err = L.RemapError(rc, "rmx_kpe_status", f"a frame of this step has {maxk} keypoints > kmax={self.kmax}")
         rc, fl = ctx.kpm_status()
-        if rc:
-            raise L.RemapError(rc, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
-        return nfrag
+        if kpe_err is not None:
+            raise kpe_err
+        if fl & ~(128 | L.RMX_KPM_REMOTE_FAILURE):
+            raise L.RemapError(L.RMX_ERR_CAPACITY, "rmx_kpm_status", f"matcher workspace limit, flags={fl}")
+        if fl & L.RMX_KPM_REMOTE_FAILURE:
+            raise L.RemapError(L.RMX_ERR_CAPACITY, "rmx_frc_finish", "another rank's block overflowed a table or a matcher limit")
+        if fl & 128:
+            # regions / pairs the LDS matcher left to its global-memory instance (a frame with
+            # thousands of keypoints in one region): tickets computed there, offsets rewritten,
+            # positions derived again.  On a sharded stream every rank gets here if one does
+            # (the flag travels with the scan summaries), so the collectives below pair up.
+            desc, kcount, dxdy, matched = out["desc"], out["kcount"], out["dxdy"], out["matched"]
+            ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
+            if self.world == 1:
+                pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
+                nfrag = carry[1] + 1
+            else:
+                pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
+                summ = _all_gather_flat(mine, self.world, self.dist, self.group)
+                ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
+                nfrag = ctx.frc_finish()
+                ctx.kpm_status()  # (the flag of the first pass, gathered again)
+            out.update(pos=pos, frag=frag, nfrag=nfrag)
+
+    def _settle(self):
+        """Complete the deferred step, if there is one: wait for it, check it, resolve it."""
+        if self._deferred is None:
+            return self._last_nfrag
+        out, halo = self._deferred
+        self._deferred = None
+        out["nfrag"] = self.ctx.frc_finish()
+        self._check_step(out, halo)
+        self._last_nfrag = out["nfrag"]
+        return self._last_nfrag
+
+    def finish(self):
+        """Wait for the deferred step: its fragment count; raises if it overflowed a table or a matcher
+        limit (every deferred step is settled before the next one starts on the same Aligner, so the
+        error names the step it belongs to)."""
+        return self._settle()
 
     def gather_positions(self, out):
         """pos_all / frag_all: positions and fragment ids of the WHOLE stream on every rank
@@ -417,6 +445,7 @@ class AlignerPipe:
         self._turn += 1
         s = self.streams[i]
         s.wait_stream(t.cuda.current_stream(self.device))  # the frames were produced there
+        frames.record_stream(s)  # ... and are read on this lane's stream: not to be recycled under it
 
         def before_kpe():
             if self._kpe_done is not None:
@@ -435,13 +464,18 @@ class AlignerPipe:
         t = self.torch
         used = min(self._turn, len(self.lanes))
         last = (self._turn - 1) % len(self.lanes) if self._turn else 0
-        nfrag = None
-        for i in range(used):
-            with t.cuda.stream(self.streams[i]):
-                r = self.lanes[i].finish()
-            if i == last:
-                nfrag = r
+        nfrag, err = None, None
+        for i in range(used):  # every lane is joined before an error is raised
+            try:
+                with t.cuda.stream(self.streams[i]):
+                    r = self.lanes[i].finish()
+                if i == last:
+                    nfrag = r
+            except L.RemapError as e:
+                err = err or e
             t.cuda.current_stream(self.device).wait_stream(self.streams[i])
+        if err is not None:
+            raise err
         return nfrag
 
     # ---- blocks with host-side stages (canvas blit, codec): submit / drain -------------------------

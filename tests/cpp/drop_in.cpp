@@ -256,8 +256,9 @@ int main(int argc, char** argv) {
     unsigned long long s = 0;
     for (auto const* d = dots.data(); d < dots.end(); ++d)
       for (int b = 0; b < 16; ++b) s = s * 1000003ull + (*d)[b];
-    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu\n", fi, f.dimensions().width_,
-                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), s);
+    auto const mg = f.margins();  // fgm.hpp:145-153
+    std::printf("fragment %zu dims %zu %zu zero %d %d frames %zu sum %llu margins %zu %zu %zu %zu\n", fi, f.dimensions().width_,
+                f.dimensions().height_, f.zero().x_, f.zero().y_, f.frames().size(), s, mg.left_, mg.top_, mg.right_, mg.bottom_);
     for (auto& fr : f.frames())
       std::printf("frame %zu frag %zu pos %d %d packed %zu %zu\n", fr.number_, fi, fr.position_.x_, fr.position_.y_,
                   fr.data_.image_.size(), fr.data_.median_.size());

@@ -321,6 +321,11 @@ class RefFragment:
         self.lib.ref_frag_frames(self.h, ptr(nums), ptr(pos))
         return nums, pos
 
+    def margins(self):
+        out = np.zeros(4, np.uint64)
+        self.lib.ref_frag_margins(self.h, ptr(out))
+        return tuple(int(v) for v in out)
+
     def blend(self):
         w, h, *_ = self.info()
         img = np.zeros((h, w), np.uint8)
@@ -462,3 +467,19 @@ def orc_fdf_filter(frames):
             orc_fgm_blit_masked(res, (zx, zy), frames[i], masks[i], p)
         canvases.append(res)
     return dict(nfrag=nfrag, masks=masks, ncontours=ncont, frag=o["frag"], canvases=canvases)
+
+
+def orc_fgm_margins(canvas):
+    """fragment::margins (fgm.hpp:145-153,235-295) restated on a (h, w, 16) canvas: (left, top, right,
+    bottom) = the fewest empty dots before the first / after the last non-empty dot of any row
+    (column); a side keeps the canvas width (height) where no row (column) has a dot."""
+    m = (np.asarray(canvas).reshape(canvas.shape[0], canvas.shape[1], -1) != 0).any(axis=2)
+    h, w = m.shape
+    rows, cols = m.any(axis=1), m.any(axis=0)
+    if not rows.any():
+        return (w, h, w, h)
+    left = int(m[rows].argmax(axis=1).min())
+    right = int(m[rows][:, ::-1].argmax(axis=1).min())
+    top = int(m[:, cols].argmax(axis=0).min())
+    bottom = int(m[::-1][:, cols].argmax(axis=0).min())
+    return (left, top, right, bottom)

@@ -121,6 +121,7 @@ def check_collect(exe, frames, tmp_path):
         for i in np.nonzero(sel)[0]:
             O.orc_fgm_blit(can, (zx, zy), frames[i], o["pos"][i])
         assert int(fl[11]) == poly_sum(can)
+        assert tuple(int(v) for v in fl[13:17]) == O.orc_fgm_margins(can)  # fragment::margins (fgm.hpp:145-153)
     for fl in frame_lines:
         i, f = int(fl[1]), int(fl[3])
         assert f == o["frag"][i]

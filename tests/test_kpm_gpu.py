@@ -316,6 +316,54 @@ def test_aligner_resolves_huge_regions_by_itself(gpu):
     al.close()
 
 
+def test_deferred_steps_resolve_huge_regions(gpu):
+    """The deferred (pipelined) path settles every step before its lane is used again: a block whose
+    tickets were left to rmx_kpm_resolve is resolved and scanned again, exactly like the synchronous
+    path — on one Aligner with steps enqueued back to back, and through AlignerPipe (the bench's
+    headline path), where a later block on the same lane would otherwise reset the work list."""
+    import torch
+
+    from remap_amd.pipeline import Aligner, AlignerPipe
+
+    frames, _ = scroller_v1(10, dens=100)
+    frames = frames.copy()
+    frames[3] = _boxnoise(17)
+    frames[4] = _boxnoise(17, shift=3)
+    plain, _ = scroller_v1(10, dens=100)
+    o_big, o_plain = O.orc_frc(frames), O.orc_frc(plain)
+    d_big, d_plain = torch.from_numpy(frames).cuda(), torch.from_numpy(plain).cuda()
+
+    def same(out, o):
+        return (np.array_equal(out["dxdy"].cpu().numpy(), o["dxdy"]) and np.array_equal(out["pos"].cpu().numpy(), o["pos"])
+                and np.array_equal(out["frag"].cpu().numpy(), o["frag"]) and out["nfrag"] == int(o["frag"].max()) + 1)
+
+    al = Aligner(320, 240, kmax=16384)
+    al.align(d_plain, defer=True)
+    out = al.align(d_big, defer=True)
+    snap = {k: (v.clone() if hasattr(v, "clone") else v) for k, v in out.items()}  # (settled when the next step starts)
+    al.align(d_plain, defer=True)
+    snap.update(pos=out["pos"].clone(), frag=out["frag"].clone(), dxdy=out["dxdy"].clone(), nfrag=out["nfrag"])
+    assert same(snap, o_big)
+    last = al.align(d_big, defer=True)
+    assert al.finish() == int(o_big["frag"].max()) + 1 and same(last, o_big)
+    al.close()
+
+    pipe = AlignerPipe(320, 240, kmax=16384, lanes=2)
+    outs = []
+    for blk in (d_plain, d_big, d_big, d_plain, d_big):
+        out = pipe.align(blk)
+        outs.append((out, o_big if blk is d_big else o_plain))
+    # lanes alternate: blocks 0, 2, 4 on lane 0 and 1, 3 on lane 1; a lane's buffers hold its LAST block
+    assert pipe.finish() == int(o_big["frag"].max()) + 1
+    assert same(outs[4][0], outs[4][1]) and same(outs[3][0], outs[3][1])
+    # through submit / drain every block is returned complete
+    pipe.submit(d_big)
+    done = [pipe.submit(d_plain), pipe.submit(d_big)] + pipe.drain()
+    done = [d for d in done if d is not None]
+    assert len(done) == 3 and same(done[0], o_big) and same(done[1], o_plain) and same(done[2], o_big)
+    pipe.close()
+
+
 @pytest.mark.parametrize("n,kind", [(1, "random"), (13, "random"), (14, "random"), (5000, "random"), (5088, "few"), (120000, "random"),
                                     (90000, "few"), (400000, "random"), (30000, "equal")])
 def test_unordered_map_order_replay_at_scale(gpu, n, kind):

@@ -181,8 +181,18 @@ def _worker_resolve(rank, world, port, q):
     frames = _huge_region_stream()
     n = len(frames)
     lo, hi = shard_range(n, rank, world)
-    al = Aligner(320, 240, kmax=16384, dist=dist)
-    out = al.align(torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda(), n_total=n)
+    local = torch.from_numpy(np.ascontiguousarray(frames[lo:hi])).cuda()
+    if os.environ.get("RMX_TEST_PIPE"):  # the pipelined path: two lanes sharing the process group
+        from remap_amd.pipeline import AlignerPipe
+
+        al = AlignerPipe(320, 240, kmax=16384, dist=dist, lanes=2)
+        al.align(local, n_total=n)
+        al.align(local, n_total=n)
+        out = al.align(local, n_total=n)
+        out["nfrag"] = al.finish()
+    else:
+        al = Aligner(320, 240, kmax=16384, dist=dist)
+        out = al.align(local, n_total=n)
     q.put((rank, lo, hi, out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy(), out["pos"].cpu().numpy(),
            out["frag"].cpu().numpy(), out["nfrag"]))
     al.close()
@@ -191,11 +201,16 @@ def _worker_resolve(rank, world, port, q):
 
 
 @pytest.mark.timeout(600)
-def test_two_ranks_resolve_a_huge_region_together(gpu):
+@pytest.mark.parametrize("pipelined", [False, True])
+def test_two_ranks_resolve_a_huge_region_together(gpu, pipelined, monkeypatch):
     """Only rank 1's block holds frames with more than 4 096 keypoints in one grid region.  The
     flag travels with the scan summaries: both ranks take the resolve-and-scan-again path (a
-    no-op on rank 0), their collectives pair up, and the result equals the oracle's."""
+    no-op on rank 0), their collectives pair up, and the result equals the oracle's — also when the
+    blocks go through AlignerPipe (deferred steps, settled before a lane is used again)."""
     import torch.multiprocessing as mp
+
+    if pipelined:
+        monkeypatch.setenv("RMX_TEST_PIPE", "1")
 
     import orclib as O
 

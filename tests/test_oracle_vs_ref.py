@@ -70,6 +70,27 @@ def test_fragment_random_blits():
     assert np.array_equal(can, f.dots())
     a, b = O.orc_fgm_blend(can), f.blend()
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    assert O.orc_fgm_margins(can) == f.margins()
+
+
+def test_fragment_margins_equal_reference():
+    """fragment::margins (fgm.hpp:145-153,235-295) on canvases with empty borders of every kind: the
+    restatement the GPU test checks the drop-in layer against must agree with the reference itself"""
+    rng = np.random.default_rng(103)
+    assert O.RefFragment(16, 8).margins() == O.orc_fgm_margins(np.zeros((8, 16, 16), np.uint16))  # nothing blitted
+    for case in range(12):
+        f = O.RefFragment(32, 16)
+        blank = np.zeros((16, 32), np.uint8)
+        n = int(rng.integers(1, 6))
+        pos = rng.integers(-70, 71, size=(n, 2)).astype(np.int32)
+        for i in range(n):
+            f.blit(pos[i], blank, i)  # (bin 0 counts too: every blitted dot is non-empty)
+        cw, ch, zx, zy = f.info()[:4]
+        can = np.zeros((ch, cw, 16), np.uint16)
+        for i in range(n):
+            O.orc_fgm_blit(can, (zx, zy), blank, pos[i])
+        assert np.array_equal(can, f.dots())
+        assert O.orc_fgm_margins(can) == f.margins(), (case, pos.tolist())
 
 
 def test_reference_reads_our_fragment_files(tmp_path):
