@@ -23,7 +23,7 @@ import numpy as np
 from . import lib as L
 
 __all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets", "sum_subcanvases",
-           "fold_block_summaries", "gather_block_rows"]
+           "fold_block_summaries", "gather_block_rows", "canvas_boxes"]
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -141,6 +141,23 @@ def sum_subcanvases(sub, zero, gbox, dist, group=None, device=None):
     dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=group)
     whole = (acc & 0xffff).to(t.int16)  # int32 -> int16 keeps the low 16 bits
     return whole if device is None else whole.to(device)
+
+
+def canvas_boxes(pos, starts, W, H):
+    """Canvas boxes of fragments that are runs of the stream: pos (n, 2) integer positions, starts = first
+    frame of every run.  Returns (w, h, zero_x, zero_y) arrays.  fgm.hpp:190-233 grows the canvas by whole
+    steps (W, H) on the side a blit sticks out of, starting from one step at the origin; the result does
+    not depend on the order of the blits: left edge = -(smallest multiple of W covering -min x), right edge
+    = W + (smallest multiple covering max x), and the same in y — what rmx_fgm_extent replays frame by frame."""
+    pos = np.asarray(pos, np.int64)
+    mn = np.minimum.reduceat(pos, starts, axis=0)
+    mx = np.maximum.reduceat(pos, starts, axis=0)
+    step = np.array([W, H], np.int64)
+    ceil_steps = lambda v: -(-v // step) * step  # smallest multiple of the step covering v >= 0
+    zero = -ceil_steps(np.maximum(-mn, 0))
+    far = step + ceil_steps(np.maximum(mx, 0))
+    dims = far - zero
+    return dims[:, 0], dims[:, 1], zero[:, 0], zero[:, 1]
 
 
 class Aligner:
@@ -318,92 +335,101 @@ class Aligner:
         allr = gather_block_rows(rows, counts, self.dist, self.group)
         out["pos_all"], out["frag_all"] = allr[:, :2].contiguous(), allr[:, 2].contiguous()
 
-    def _blit_one(self, frames, pos, frag, fid, loc, ext, fa, fb, pa, pb):
-        """One fragment's sub-canvas: frames[fa:fb] at pos[pa:pb] (filtered by `frag` == fid when
-        given); `loc` = the host copy of those positions, `ext` = the fragment's global box."""
-        t = self.torch
-        gw, gh, gzx, gzy = ext
-        # step-aligned sub-box (in steps from the global zero) covering the local frames
-        x0 = (int(loc[:, 0].min()) - gzx) // self.W * self.W
-        y0 = (int(loc[:, 1].min()) - gzy) // self.H * self.H
-        x1 = -((-(int(loc[:, 0].max()) + self.W - gzx)) // self.W) * self.W
-        y1 = -((-(int(loc[:, 1].max()) + self.H - gzy)) // self.H) * self.H
-        cw, ch, zx, zy = x1 - x0, y1 - y0, gzx + x0, gzy + y0
-        key = ("canvas", int(fid))
-        c = self._bufs.get(key)
-        if c is None or tuple(c.shape) != (ch, cw, 16):
-            c = t.empty((ch, cw, 16), dtype=t.int16, device=self.ctx.device)
-            self._bufs[key] = c
-        if self.blit_gate is not None:  # (AlignerPipe: the blit kernels wait for the other lane's extraction)
-            self.blit_gate()
-        c.zero_()
-        self.ctx.fgm_blit(frames[fa:fb], pos[pa:pb], c, (zx, zy), frag_id=frag, fragment=int(fid))
-        return (c, (zx, zy), (gw, gh, (gzx, gzy)))
-
     def blit(self, frames, pos, frag, lo, hi):
-        """fgm::fragment::blit of this rank's frames.  For every fragment with frames on this
-        rank the GLOBAL canvas box (zero, dims) follows from all positions of the fragment
-        (fgm.hpp:190-233); the rank accumulates only the step-aligned sub-box its own frames
-        touch.  Returns {fragment: (canvas, zero, (global_w, global_h, global_zero))}: adding
-        every rank's sub-canvas at (zero - global_zero) with uint16 wraparound gives the
-        reference canvas (fgm.hpp:99-113); with one rank the sub-box is the whole box."""
+        """fgm::fragment::blit of this rank's frames into the canvases of ALL fragments of the stream.
+
+        The canvas box of a fragment (zero, dims) follows from all its positions (fgm.hpp:190-233: the
+        smallest box of whole steps around the frame at (0, 0) that covers every blit; `canvas_boxes`
+        is that rule in closed form, vectorised over the fragments).  Fragments of equal canvas height
+        are laid side by side in ONE wide canvas (64-pixel aligned), so a block is blitted with one
+        zeroed allocation and one rmx_fgm_blit_batch launch per distinct height — the column bins of the
+        kernel then separate the fragments by themselves — instead of an extent call, a memset and a
+        launch per fragment (a stream with hundreds of fragments spent its time in that host loop).
+        Returns {fragment: (canvas, zero, (w, h, zero))}: `canvas` is a (h, w, 16) int16 view into the
+        stacked buffer (rows are strided; `.contiguous()` for the C ABI).  On a sharded stream every rank
+        holds the same layout and has counted only its own frames: the bin-wise sum modulo 2^16 over the
+        ranks of the one flat buffer (`sum_canvases`) is the reference's canvas (fgm.hpp:99-113)."""
         t = self.torch
+        W, H = self.W, self.H
         # positions and fragment ids in ONE copy to the host (one wait instead of two)
         both = t.cat([pos, frag.to(t.int32)[:, None]], dim=1).cpu().numpy()
-        pos_h, frag_h = both[:, :2], both[:, 2]
-        canvases = {}
-        # a fragment's frames are one run of the stream (frc.hpp:97-115: ids count the cuts), so a
-        # fragment is a slice of the batch: no masks, no per-frame fragment test in the kernel
+        pos_h, frag_h = both[:, :2].astype(np.int64), both[:, 2]
+        # a fragment's frames are one run of the stream (frc.hpp:97-115: ids count the cuts)
         cuts = np.flatnonzero(frag_h[1:] != frag_h[:-1]) + 1
-        starts = np.concatenate([[0], cuts])
-        ends = np.concatenate([cuts, [len(frag_h)]])
-        runs_ok = len(np.unique(frag_h[starts])) == len(starts)
-        for a, b in zip(starts, ends):
-            if not runs_ok:
-                break
-            la, lb = max(int(a), lo), min(int(b), hi)
-            if la >= lb:
-                continue
-            fid = int(frag_h[a])
-            gw, gh, gzx, gzy = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[a:b]))
-            canvases[fid] = self._blit_one(frames, pos, None, fid, pos_h[la:lb], (gw, gh, gzx, gzy), la - lo, lb - lo, la, lb)
-        if not runs_ok:  # (ids out of order: select by mask)
-            pos_l = pos[lo:hi].contiguous()
-            frag_l = frag[lo:hi].contiguous()
-            for fid in np.unique(frag_h[lo:hi]):
-                sel = frag_h == fid
-                ext = self.ctx.fgm_extent(np.ascontiguousarray(pos_h[sel]))
-                loc = pos_h[lo:hi][frag_h[lo:hi] == fid]
-                canvases[int(fid)] = self._blit_one(frames, pos_l, frag_l, int(fid), loc, ext, 0, hi - lo, 0, hi - lo)
+        starts = np.concatenate([[0], cuts]).astype(np.int64)
+        fids = frag_h[starts]
+        assert len(np.unique(fids)) == len(fids), "fragment ids are not runs of the stream"
+        gw, gh, gzx, gzy = canvas_boxes(pos_h, starts, W, H)
+        # classes of equal height, fragments side by side
+        heights, cls_of = np.unique(gh, return_inverse=True)
+        wpad = -(-gw // 64) * 64
+        xoff = np.zeros(len(fids), np.int64)
+        wtot = np.zeros(len(heights), np.int64)
+        for c in range(len(heights)):  # (a handful of classes; the fragments inside one are vectorised)
+            m = cls_of == c
+            xoff[m] = np.cumsum(wpad[m]) - wpad[m]
+            wtot[c] = int(wpad[m].sum())
+        dots = heights.astype(np.int64) * wtot
+        base = np.concatenate([[0], np.cumsum(dots)])
+        flat = self._bufs.get("canvas_flat")
+        if flat is None or flat.numel() != int(base[-1]) * 16:
+            flat = t.empty(int(base[-1]) * 16, dtype=t.int16, device=self.ctx.device)
+            self._bufs["canvas_flat"] = flat
+        if self.blit_gate is not None:  # (AlignerPipe: the blit kernels wait for the other lane's extraction)
+            self.blit_gate()
+        flat.zero_()
+        stacked = [flat[int(base[c]) * 16:int(base[c + 1]) * 16].view(int(heights[c]), int(wtot[c]), 16) for c in range(len(heights))]
+        # this rank's frames: position inside the stacked canvas of their class, and the class
+        run_of = np.searchsorted(starts, np.arange(lo, hi), side="right") - 1
+        adj = np.empty((hi - lo, 3), np.int32)
+        adj[:, 0] = pos_h[lo:hi, 0] - gzx[run_of] + xoff[run_of]
+        adj[:, 1] = pos_h[lo:hi, 1] - gzy[run_of]
+        adj[:, 2] = cls_of[run_of]
+        dev = t.from_numpy(adj).to(self.ctx.device)
+        apos, acls = dev[:, :2].contiguous(), dev[:, 2].contiguous()
+        for c in np.unique(adj[:, 2]):
+            self.ctx.fgm_blit(frames, apos, stacked[int(c)], (0, 0), frag_id=acls, fragment=int(c))
+        canvases = {}
+        for i, fid in enumerate(fids):
+            c = int(cls_of[i])
+            box = (int(gw[i]), int(gh[i]), (int(gzx[i]), int(gzy[i])))
+            canvases[int(fid)] = (stacked[c][:, int(xoff[i]):int(xoff[i]) + int(gw[i])], box[2], box)
+        self._layout = (flat, fids, starts)
         return canvases
 
-    def fragments(self, frames, out):
-        """collector.complete() for a sharded stream: the whole canvas of every fragment on
-        every rank, as splice.Fragment objects (normalised: zero = (0, 0), fgm.hpp:137-143).
+    def sum_canvases(self):
+        """The stacked canvases of the last `blit`, summed over the ranks in place: ONE all-reduce for all
+        fragments.  RCCL has no 16-bit integer type, so the bins travel as int32 (the sum of at most
+        `world` uint16 values cannot overflow) and are narrowed again — exact modulo 2^16."""
+        if self.world == 1:
+            return
+        t = self.torch
+        flat = self._layout[0]
+        gloo = self.dist.get_backend(self.group) == "gloo"
+        wide = (flat.to(t.int32) & 0xffff)
+        if gloo:
+            wide = wide.cpu()
+        self.dist.all_reduce(wide, op=self.dist.ReduceOp.SUM, group=self.group)
+        flat.copy_((wide & 0xffff).to(t.int16))  # int32 -> int16 keeps the low 16 bits
 
-        Each rank has blitted its own frames into step-aligned sub-boxes (`blit`); the
-        reference canvas is their bin-wise sum modulo 2^16 (`sum_subcanvases`)."""
+    def fragments(self, frames, out):
+        """collector.complete() for a (sharded) stream: the whole canvas of every fragment on every
+        rank, as splice.Fragment objects (normalised: zero = (0, 0), fgm.hpp:137-143)."""
         from .splice import Fragment
 
-        t = self.torch
         self.gather_positions(out)
         canv = out.get("canvases")
         if canv is None:
             canv = self.blit(frames, out["pos_all"], out["frag_all"], out["lo"], out["hi"])
+        self.sum_canvases()
         pos_h = out["pos_all"].cpu().numpy()
-        frag_h = out["frag_all"].cpu().numpy()
+        _, fids, starts = self._layout
+        ends = np.concatenate([starts[1:], [len(pos_h)]])
         result = []
-        for fid in range(int(out["nfrag"])):
-            sel = np.nonzero(frag_h == fid)[0]
-            gw, gh, gzx, gzy = self.ctx.fgm_extent(pos_h[sel])
-            mine = canv.get(fid)
-            if self.world == 1:
-                whole = mine[0]
-            else:
-                whole = sum_subcanvases(None if mine is None else mine[0], None if mine is None else mine[1],
-                                        (gw, gh, gzx, gzy), self.dist, self.group, self.ctx.device)
-            frames_list = [(int(i), (int(pos_h[i, 0]) - gzx, int(pos_h[i, 1]) - gzy)) for i in sel]
-            result.append(Fragment(whole, (0, 0), (self.W, self.H), frames_list))
+        for fid, a, b in zip(fids, starts, ends):
+            canvas, (gzx, gzy), _ = canv[int(fid)]
+            frames_list = [(int(i), (int(pos_h[i, 0]) - gzx, int(pos_h[i, 1]) - gzy)) for i in range(int(a), int(b))]
+            result.append(Fragment(canvas.contiguous(), (0, 0), (self.W, self.H), frames_list))
         return result
 
     def close(self):

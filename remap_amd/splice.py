@@ -122,6 +122,41 @@ def _extract_single(ctx_cache, frag, device):  # fgs.hpp:80-89
         return _Snippet(frag, mask, desc[0], int(kc[0].item()))
 
 
+def _extract_all(ctx_cache, frags):  # fgs.hpp:91-103
+    """extract_single for every fragment, batched: the blends are enqueued one after the other (no host
+    wait between them), fragments of equal canvas size share ONE rmx_kpe_batch launch and ONE status /
+    count read-back (the reference runs them under std::execution::par; a stream with hundreds of
+    fragments otherwise pays a device round trip per fragment before the first pair is scored)."""
+    import torch
+
+    any_ctx = ctx_cache("any")
+    blends = [any_ctx.fgm_blend(f.canvas) for f in frags]
+    groups = {}
+    for i, f in enumerate(frags):
+        groups.setdefault(f.dims, []).append(i)
+    snippets = [None] * len(frags)
+    for (w, h), idx in groups.items():
+        imgs = torch.stack([blends[i][0] for i in idx])
+        kmax = SNIPPET_KMAX
+        while True:
+            kctx = ctx_cache((w, h, kmax))
+            _, desc, kc = kctx.kpe(imgs)
+            rc, maxk = kctx.kpe_status()
+            if rc == L.RMX_ERR_KMAX and maxk <= SNIPPET_KMAX_LIMIT:  # same canvases, larger tables
+                while kmax < maxk:
+                    kmax *= 2
+                continue
+            if rc:
+                raise L.RemapError(rc, "rmx_kpe_status",
+                                   f"a fragment of {w}x{h} has {maxk} keypoints; a descriptor table holds at most "
+                                   f"{SNIPPET_KMAX_LIMIT}")
+            break
+        ks = kc.cpu().numpy()
+        for j, i in enumerate(idx):
+            snippets[i] = _Snippet(frags[i], blends[i][1], desc[j], int(ks[j]))
+    return snippets
+
+
 def splice(fragments, device=0, dist=None, group=None):
     """fgs::splice over a list of normalised Fragments (collector.complete()).  Returns the
     spliced fragments in the reference's list order.
@@ -139,7 +174,7 @@ def splice(fragments, device=0, dist=None, group=None):
         return ctxs[key]
 
     mctx = ctx_cache("any")
-    snippets = [_extract_single(ctx_cache, f, device) for f in fragments]  # extract_all, fgs.hpp:91-103
+    snippets = _extract_all(ctx_cache, fragments)
 
     def score(members, pairs):
         """votes of `pairs` (indices into `members`), scored on this rank's share only"""

@@ -52,9 +52,9 @@ def test_ten_thousand_frames(gpu, dens):
 
 
 def test_deferred_steps_equal_synchronous_ones(gpu):
-    """Aligner.align(defer=True): steps enqueued back to back, one host wait in finish() — same
-    offsets, positions, fragment ids and fragment count as the synchronous step; an overflow in
-    any deferred step surfaces in finish()."""
+    """Aligner.align(defer=True): steps enqueued back to back, settled one step late (or in finish()) —
+    same offsets, positions, fragment ids and fragment count as the synchronous step; an overflow in a
+    deferred step surfaces when that step is settled: before the next step reuses its buffers."""
     import torch
 
     from remap_amd.pipeline import Aligner
@@ -74,13 +74,15 @@ def test_deferred_steps_equal_synchronous_ones(gpu):
     for k, v in want.items():
         assert torch.equal(out[k], v), k
     al.close()
-    # sticky status: a table overflow in the FIRST of three deferred steps is reported at the end
+    # a table overflow in a deferred step is reported for THAT step: when the next one starts, or in finish()
     rng = np.random.default_rng(1)
     noise = torch.from_numpy(rng.integers(0, 16, size=(4, 240, 320), dtype=np.uint8)).cuda()
-    al = Aligner(320, 240, kmax=256)
+    al = Aligner(320, 240, kmax=512)  # (the scroller's frames have ~270 keypoints, the noise 46 000)
     al.align(noise, defer=True)
-    al.align(d[:4].contiguous(), defer=True)
-    al.align(d[:4].contiguous(), defer=True)
+    with pytest.raises(L.RemapError):
+        al.align(d[:4].contiguous(), defer=True)
+    assert al.align(d[:4].contiguous(), defer=True)["nfrag"] is None and al.finish() == 1  # (the Aligner goes on)
+    al.align(noise, defer=True)
     with pytest.raises(L.RemapError):
         al.finish()
     al.close()
@@ -127,11 +129,13 @@ def test_blocks_in_flight_equal_blocks_one_by_one(gpu):
         pipe.close()
     rng = np.random.default_rng(1)
     noise = torch.from_numpy(rng.integers(0, 16, size=(4, 240, 320), dtype=np.uint8)).cuda()
-    pipe = AlignerPipe(320, 240, kmax=256, lanes=2)
+    pipe = AlignerPipe(320, 240, kmax=512, lanes=2)
     pipe.align(noise)
     pipe.align(blocks[0][:4].contiguous())
-    pipe.align(blocks[0][:4].contiguous())
-    with pytest.raises(L.RemapError):
+    with pytest.raises(L.RemapError):  # lane 0 is used again: its block is settled first
+        pipe.align(blocks[0][:4].contiguous())
+    pipe.align(noise)
+    with pytest.raises(L.RemapError):  # ... or in finish(), after every lane has been joined
         pipe.finish()
     pipe.close()
 

@@ -179,3 +179,27 @@ def test_bitplane_3x3_pass_matches_oracle(tmp_path):
         inner = np.zeros((Hh, Ww), bool)
         inner[2:Hh - 4, 2:Ww - 2] = True
         assert np.array_equal(cand.astype(bool), (omed != fr) & inner)
+
+
+def test_canvas_boxes_equal_the_frame_by_frame_growth():
+    """pipeline.canvas_boxes (closed form, all fragments at once) against rmx_fgm_extent's replay of
+    fgm.hpp:190-233 and the oracle's, on random walks incl. ones that never leave the first step"""
+    from remap_amd.pipeline import canvas_boxes
+
+    rng = np.random.default_rng(7)
+    so = L.load()
+    for W, H in ((320, 240), (64, 32), (17, 5)):
+        runs, pos = [], []
+        for _ in range(40):
+            n = int(rng.integers(1, 30))
+            scale = int(rng.choice([1, 3, 40, 400]))
+            p = np.cumsum(rng.integers(-scale, scale + 1, size=(n, 2)), axis=0)
+            p[0] = 0
+            runs.append(len(pos))
+            pos += p.tolist()
+        pos = np.array(pos, np.int64)
+        starts = np.array(runs, np.int64)
+        gw, gh, zx, zy = canvas_boxes(pos, starts, W, H)
+        ends = list(starts[1:]) + [len(pos)]
+        for i, (a, b) in enumerate(zip(starts, ends)):
+            assert O.orc_fgm_extent(pos[a:b].astype(np.int32), W, H) == (gw[i], gh[i], zx[i], zy[i])
