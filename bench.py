@@ -14,14 +14,20 @@ tables and per-frame offsets are all-gathered over RCCL, and the result is the g
 alignment.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     — kpe_mf (the dominant kernel: keypoint extraction, streaming pass and 5x5 finish
-                 in one launch): algorithmic bytes (2*W*H + 18*K per frame) / its
-                 average launch time from HIP events on the launch stream, against the 8 TB/s HBM
-                 peak; `pair` = the two-kernel form of rounds 1-2a (kpe_main + kpe_finish) timed
-                 on the same box for reference (its kpe_main alone is what round 1 reported);
+  roofline     — kpe_bs (the dominant kernel: keypoint extraction — 3x3 pass on bit planes and 5x5
+                 finish in one launch): algorithmic bytes (2*W*H + 18*K per frame) /
+                 its average launch time from HIP events on the launch stream, against the 8 TB/s
+                 HBM peak; `previous_kernels` = kpe_mf (round 2) and the two-kernel form of rounds
+                 1-2a, timed in this run on this box.  Every figure is measured in the run, except
+                 `traffic` and `valu_wave_instructions`, which come from the committed rocprofv3 --pmc
+                 passes named in `*_source` (counters cannot be read from inside the process);
+  workloads    — the other BASELINE.json workloads, timed in this run (value + the extraction kernel's
+                 roofline fraction each): dense stream, 640x480 native and pixel-doubled, rooms
+                 (collect with canvas blit, then fgs::splice);
   cpu_baseline — the reference's own frc::collector::collect (oracle/_ref, built from
                  /root/reference by oracle/build_ref.sh) or, if that library is absent, the
-                 CPU restatement (oracle/), timed on one host core on the same frames.
+                 CPU restatement (oracle/), timed on one host core on the same frames; `all_cores` =
+                 SURVEY.md §8d (ii): frame-parallel kpe on every host core + sequential kpm/frc.
 """
 from __future__ import annotations
 
@@ -64,6 +70,23 @@ def cpu_baseline(frames_host):
     port = {"value": m * pa / dta, "unit": "frames/s", "cores": 1, "kind": "port", "stages": "kpe+kpm+frc",
             "sample": f"oracle/remap_oracle.cpp kpe+kpm+frc loop (scalar C++, no blit) on the first {m} frames of the "
                       f"same stream, {pa} passes, {dta:.1f} s"}
+    # kpe of the frames on all host cores (one oracle call per frame, the GIL is released
+    # inside), then the sequential part: kpm between consecutive tables + the position scan
+    from concurrent.futures import ThreadPoolExecutor
+
+    cores = os.cpu_count() or 1
+    mc = min(n, 250 * cores)
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:
+        tabs = list(ex.map(lambda f: O.orc_kpe(f)[1], frames_host[:mc]))
+    t_kpe = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for i in range(1, mc):
+        O.orc_kpm_grid(tabs[i - 1], tabs[i])
+    t_kpm = time.perf_counter() - t0
+    port["all_cores"] = {"value": mc / (t_kpe + t_kpm), "unit": "frames/s", "cores": cores, "kind": "port",
+                         "stages": "kpe (frame-parallel) + kpm/frc (sequential)",
+                         "sample": f"first {mc} frames: kpe {t_kpe:.2f} s on {cores} threads + kpm {t_kpm:.2f} s on one"}
     if O.ref_full() is not None:
         dt, passes = timed(O.ref_frc, frames_host, 10.0)
         return {"value": n * passes / dt, "unit": "frames/s", "cores": 1, "kind": "reference",
@@ -74,38 +97,126 @@ def cpu_baseline(frames_host):
     return port
 
 
-VALU_RATE_PER_NS = 558.0  # wave-instructions per ns, whole chip: v_min3/med3/max3_u32 streams, tools/micro/valu_rate.hip
-
-
-def pmc_valu(n_local, dens):
-    """VALU wave-instructions of one kpe_mf launch from the same committed PMC passes."""
+def pmc_file(n_local, dens):
+    """The committed rocprofv3 --pmc summary of the extraction kernel on this same workload
+    (profiles/*_pmc_kpe_bs.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py: FETCH_SIZE doubled,
+    WRITE_SIZE as is — MI355X_MICROARCH.md §HBM).  (None, None) if the workload differs from the profiled
+    one (10 000 frames, dens 200) or no profile is committed."""
     if n_local != FRAMES_PER_GPU or dens != DENS:
-        return None
+        return None, None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_mf.json")))
-    try:
-        return float(json.load(open(files[-1]))["counters_mean_per_launch"]["SQ_INSTS_VALU"])
-    except Exception:
-        return None
-
-
-def pmc_traffic(n_local, dens):
-    """HBM bytes per kpe_mf launch from the committed rocprofv3 --pmc passes of this same
-    workload (profiles/*_pmc_kpe_mf.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py:
-    FETCH_SIZE doubled, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM).  None if the workload
-    differs from the profiled one (10 000 frames, dens 200) or no profile is committed."""
-    if n_local != FRAMES_PER_GPU or dens != DENS:
-        return None
-    import glob
-
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_mf.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_bs.json")))
     if not files:
-        return None
+        return None, None
     try:
-        return float(json.load(open(files[-1]))["hbm_bytes_per_launch"])
+        return json.load(open(files[-1])), os.path.relpath(files[-1], ROOT)
     except Exception:
-        return None
+        return None, None
+
+
+def time_stream(torch, frames, W, H, kmax, steps, lanes, truth=None):
+    """Aligned frames/s of one more workload: `steps` blocks through AlignerPipe (as the headline), the
+    extraction kernel's launch time from HIP events on the lanes' streams, its roofline fraction."""
+    from remap_amd.pipeline import AlignerPipe
+
+    n = frames.shape[0]
+    pipe = AlignerPipe(W, H, kmax=kmax, lanes=lanes)
+    for _ in range(2 * lanes):
+        out = pipe.align(frames)
+    pipe.finish()
+    for lane in pipe.lanes:
+        lane.ctx.set_timing(2)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        out = pipe.align(frames)
+    nfrag = pipe.finish()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    nl = [lane.ctx.kernel_launches("kpe_main") for lane in pipe.lanes]
+    ms = sum(lane.ctx.kernel_ms("kpe_main") * k for lane, k in zip(pipe.lanes, nl) if k) / max(1, sum(nl))
+    ktot = int(out["kcount"].sum().item())
+    alg = 2.0 * W * H * n + 18.0 * ktot
+    rec = {"frames": n, "size": f"{W}x{H}", "value": n * steps / dt, "unit": "frames/s", "ms_per_step": dt / steps * 1e3,
+           "keypoints_per_frame": ktot / n, "fragments": nfrag, "matched_frames": int(out["matched"].sum().item()),
+           "kpe_ms": ms, "kpe_frac_of_hbm_peak": alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms > 0 else None}
+    if truth is not None:
+        dx, mt = out["dxdy"].cpu().numpy(), out["matched"].cpu().numpy()
+        rec["offsets_bit_exact_vs_truth"] = bool(mt[1:].all() and (dx[1:] == truth[1:]).all())
+    pipe.close()
+    return rec
+
+
+def other_workloads(torch, args):
+    """The BASELINE.json workloads beside the headline's, one GPU, timed in this run."""
+    from remap_amd.pipeline import Aligner
+    from remap_amd.splice import splice
+    from remap_amd.synth import rooms_v1, scroller_v1, upscale2
+
+    res = {}
+    n = args.frames
+    steps = max(4, args.steps // 2)
+    fr, truth = scroller_v1(n, W, H, dens=40)
+    res["dense"] = dict(time_stream(torch, torch.from_numpy(fr).cuda(), W, H, 2048, steps, args.lanes, truth),
+                        workload=f"{n} frames 320x240 scroller-v1 dens 40 (configs[1], dense variant)")
+    del fr
+    # configs[3]: 640x480, a stream generated at that size and the pixel-doubled 320x240 stream
+    fr, truth = scroller_v1(n, 640, 480, dens=DENS)
+    d = torch.from_numpy(fr).cuda()
+    del fr
+    res["config4_native"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes, truth),
+                                 workload=f"{n} frames 640x480 scroller-v1 generated at that size (configs[3])")
+    small, _ = scroller_v1(n, W, H, dens=DENS)
+    for i in range(0, n, 1000):  # (upscaled slice by slice: the host copy of the doubled stream would be 3 GB)
+        d[i:i + 1000] = torch.from_numpy(upscale2(small[i:i + 1000])).cuda()
+    res["config4_doubled"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes),
+                                  workload=f"{n} frames 640x480 = scroller-v1 pixel-doubled (configs[3] 'upscaled capture'; a doubled "
+                                           "patch rarely yields keypoints: no frame matches, in the reference as here)")
+    al = Aligner(640, 480, kmax=4096)
+    al.align(d, blit=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        al.align(d, blit=True)
+    torch.cuda.synchronize()
+    res["config4_doubled"]["frames_per_s_with_blit"] = n * 3 / (time.perf_counter() - t0)
+    al.close()
+    del d, small
+    torch.cuda.empty_cache()
+    # configs[4]: rooms-v1, 50 000 frames on one GPU: collect with the canvas blit, then fgs::splice
+    n5 = 5 * n
+    fr, _, _ = rooms_v1(n5, W, H, n_rooms=64, dens=DENS, seed=7)
+    d = torch.from_numpy(fr).cuda()
+    del fr
+    al = Aligner(W, H, kmax=2048)
+    out = al.align(d, blit=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        out = al.align(d, blit=True)
+    torch.cuda.synchronize()
+    t_collect = (time.perf_counter() - t0) / 3
+    t0 = time.perf_counter()
+    for _ in range(3):
+        al.align(d)
+    torch.cuda.synchronize()
+    t_align = (time.perf_counter() - t0) / 3
+    frags = al.fragments(d, out)
+    nf = len(frags)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    spliced = splice(frags)
+    torch.cuda.synchronize()
+    t_splice = time.perf_counter() - t0
+    res["config5"] = {"workload": f"{n5} frames 320x240 rooms-v1 (64 rooms, each visited twice): collect (kpe+kpm+frc+fgm blit), then "
+                                  "fgs::splice (blend, kpe 1x1, all-pairs cellular kpm, greedy merges) — configs[4] on one GPU",
+                      "frames": n5, "value": n5 / t_collect, "unit": "frames/s (collect with canvas blit)",
+                      "frames_per_s_alignment_only": n5 / t_align, "fragments_collected": nf, "fragments_spliced": len(spliced),
+                      "initial_pairs": nf * (nf - 1) // 2, "splice_s": t_splice,
+                      "pair_matches_per_s": nf * (nf - 1) // 2 / t_splice}
+    al.close()
+    return res
 
 
 def main():
@@ -117,6 +228,7 @@ def main():
     ap.add_argument("--dens", type=int, default=DENS)
     ap.add_argument("--lanes", type=int, default=2, help="blocks in flight (AlignerPipe); 1: one stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the other BASELINE.json workloads (dense, 640x480, rooms)")
     ap.add_argument("--cpu-frames", type=int, default=10000)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the "
                                                       "multi-rank flow on one GPU")
@@ -237,7 +349,8 @@ def main():
     # per-step totals of the other kernels (kpm_build / kpm_match run several instances each)
     ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3
                 for k in ("kpe_table", "kpm_build", "kpm_match")}
-    # the two-kernel form (rounds 1-2a), same box, untimed part: kpe_main + kpe_finish
+    # the extraction kernels of earlier rounds on this box, untimed part: the two-kernel form (rounds 1-2a:
+    # kpe_main + kpe_finish) and kpe_mf (round 2; a context made with RMX_KPE_BS=0)
     os.environ["RMX_KPE_PAIR"] = "1"
     al.align(frames, n_total=n_total)
     al.ctx.set_timing(True)
@@ -246,6 +359,16 @@ def main():
     pair = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3 for k in ("kpe_main", "kpe_finish")}
     del os.environ["RMX_KPE_PAIR"]
     al.ctx.set_timing(False)
+    os.environ["RMX_KPE_BS"] = "0"
+    mf = L.Context(W, H, kmax=2048, device=local_rank)
+    del os.environ["RMX_KPE_BS"]
+    mf_out = mf.kpe(frames)
+    mf.set_timing(True)
+    for _ in range(5):
+        mf.kpe(frames, *mf_out)
+    ms_kpe_mf = mf.kernel_ms("kpe_main")
+    mf.close()
+    del mf_out
 
     # tier B: + fgm blit into the fragment canvases (reported beside the headline); blocks in
     # flight as above (AlignerPipe.submit / drain: the host-side stage of block t — positions to
@@ -325,11 +448,9 @@ def main():
         # (2*W*H + 18*K) x the frames one launch processes
         alg_bytes = (2.0 * W * H * n_local + 18.0 * ktot) / max(1.0, launches_per_step)
         achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
-        traffic = pmc_traffic(n_local, args.dens) if launches_per_step == 1 else None
-        valu = pmc_valu(n_local, args.dens) if launches_per_step == 1 else None
-        # what actually bounds the kernel: its VALU instruction count against the
-        # chip's measured VALU issue rate; reported beside the contract's HBM figure
-        valu_floor_ms = valu / VALU_RATE_PER_NS * 1e-6 if valu else None
+        pmc, pmc_src = pmc_file(n_local, args.dens) if launches_per_step == 1 else (None, None)
+        traffic = float(pmc["hbm_bytes_per_launch"]) if pmc else None
+        valu = float(pmc["counters_mean_per_launch"]["SQ_INSTS_VALU"]) if pmc else None
         line = {
             "metric": "aligned frames/s, 320x240 stream (kpe+kpm+frc: alignment only, no canvas blit), offsets bit-exact",
             "value": n_total * args.steps / dt,
@@ -356,24 +477,28 @@ def main():
             "frames_per_s_with_blit_one_block_in_flight": n_total * nb1 / dtb_one,
             "frames_per_s_with_blit_and_codec": n_total * nb / dtc,
             "frames_per_s_host_fed": n_total * nh / dth,
-            "kernel_ms": dict(kpe_mf=ms_kpe, **ms_parts),
+            "kernel_ms": dict(kpe_bs=ms_kpe, **ms_parts),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "kpe_mf (whole keypoint extraction: streaming 3x3 pass + 5x5 finish of the workgroup's own "
-                                   "candidates; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this workload, "
+                                            "a committed run: counters cannot be collected from inside the process)") if pmc_src else None,
+                         "kernel": "kpe_bs (whole keypoint extraction: 3x3 rank selection on bit planes, 32 pixels per lane operation, + "
+                                   "5x5 finish of the workgroup's own candidates; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "measured_in_this_run": ["achieved", "frac", "one_block_in_flight", "previous_kernels", "device_copy_gbs",
+                                                  "torch_device_copy_gbs", "algorithmic_bytes_per_launch"],
                          "one_block_in_flight": {"note": "the same kernel with the chip to itself (single stream, the K steps timed again); "
                                                          "with two blocks in flight the small kpm kernels of the previous block run beside it",
-                                                 "kpe_mf_ms": ms_kpe_one,
+                                                 "kpe_bs_ms": ms_kpe_one,
                                                  "frac": alg_bytes / (ms_kpe_one * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_kpe_one > 0 else None},
-                         "pair": {"note": "two-kernel form of rounds 1-2a on this box, same algorithmic bytes",
-                                  "kpe_main_ms": pair["kpe_main"], "kpe_finish_ms": pair["kpe_finish"],
-                                  "kpe_main_alone_frac": alg_bytes / (pair["kpe_main"] * 1e-3) / 1e9 / HBM_PEAK_GBS if pair["kpe_main"] > 0 else None,
-                                  "both_frac": alg_bytes / ((pair["kpe_main"] + pair["kpe_finish"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
-                                  if pair["kpe_main"] > 0 else None},
+                         "previous_kernels": {"note": "same box, same frames, same algorithmic bytes",
+                                              "kpe_mf_ms": ms_kpe_mf,
+                                              "kpe_mf_frac": alg_bytes / (ms_kpe_mf * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_kpe_mf > 0 else None,
+                                              "kpe_main_ms": pair["kpe_main"], "kpe_finish_ms": pair["kpe_finish"],
+                                              "kpe_main_plus_finish_frac": alg_bytes / ((pair["kpe_main"] + pair["kpe_finish"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
+                                              if pair["kpe_main"] > 0 else None},
                          "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
                          "torch_device_copy_gbs": torch_copy_gbs,
-                         "valu_wave_instructions": valu, "valu_floor_ms": valu_floor_ms,
-                         "frac_of_valu_floor": (valu_floor_ms / ms_kpe) if valu_floor_ms and ms_kpe > 0 else None,
+                         "valu_wave_instructions": valu, "valu_wave_instructions_source": pmc_src if valu else None,
                          "algorithmic_bytes_per_launch": alg_bytes},
         }
         if world == 1 and not args.no_cpu:
@@ -387,9 +512,16 @@ def main():
                                    "cpu_frames_per_s": (cb.get("alignment_only") or cb)["value"], "cpu_kind": "port"}}
         else:
             line["cpu_baseline"] = None
+        if world == 1 and not args.no_workloads:
+            al.close()
+            pipe.close()
+            del frames
+            torch.cuda.empty_cache()
+            line["workloads"] = other_workloads(torch, args)
         print(json.dumps(line), flush=True)
-    al.close()
-    pipe.close()
+    if not (rank == 0 and world == 1 and not args.no_workloads):
+        al.close()
+        pipe.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -354,5 +354,43 @@ def main():
     print("cell pairs:", [cell[f"res{i}"].tolist() for i in range(ci)])
 
 
+def golden_rooms():
+    """BASELINE.json configs[4] in small: a 2 000-frame rooms-v1 stream at 320x240 through the REFERENCE's
+    collect (frc.hpp) and splice (fgs.hpp:187-213): 80 fragments, 16 merges — the greedy loop's
+    select_match order and the re-matching after every merge are exercised sixteen times — plus the
+    reference's cellular kpm::match votes (kpm.hpp:371-393, unmodified tier) for all 3 160 initial pairs."""
+    gen = (2000, 320, 240, 20, 200, 11)
+    n, w, h, rooms, dens, seed = gen
+    fr, _, _ = rooms_v1(n, width=w, height=h, n_rooms=rooms, dens=dens, seed=seed)
+    sp = O.ref_frc_splice(fr)
+    col = O.ref_frc(fr)
+    nf = int(col["frag"].max()) + 1
+    assert nf == sp["ncollected"]
+    tabs = []
+    for f in range(nf):
+        idx = np.nonzero(col["frag"] == f)[0]
+        rf = O.RefFragment(w, h)
+        for i in idx:
+            rf.blit(col["pos_norm"][i], fr[i], int(i))
+        assert rf.info()[:2] == tuple(col["dims"][f].tolist())
+        img, mask = rf.blend()
+        _, desc, _ = O.ref_kpe(img, True)
+        tabs.append((mask, desc))
+    pairs = [(i, j) for i in range(nf) for j in range(i + 1, nf)]
+    votes = np.zeros((len(pairs), 4), np.int32)
+    for k, (i, j) in enumerate(pairs):
+        m, v = O.ref_kpm_cell(tabs[i][1], tabs[i][0], tabs[j][1], tabs[j][0].shape)
+        votes[k] = (v["dx"], v["dy"], v["count"], 1) if m else (0, 0, 0, 0)
+    np.savez_compressed(os.path.join(OUT, "fgs_splice_rooms.npz"), input_sha256=np.frombuffer(bytes.fromhex(sha(fr)), np.uint8),
+                        gen=np.array(gen), nfrag=np.array(sp["nfrag"]), ncollected=np.array(sp["ncollected"]), frag=sp["frag"],
+                        pos=sp["pos"], dims=sp["dims"], canvas_sum=sp["canvas_sum"], collected_frag=col["frag"],
+                        collected_dims=col["dims"], votes=votes, kcounts=np.array([len(t[1]) for t in tabs]))
+    print("rooms: collected", sp["ncollected"], "-> spliced", sp["nfrag"], "valid initial votes", int(votes[:, 3].sum()), "of", len(pairs))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "rooms":
+        golden_rooms()
+    else:
+        main()
+        golden_rooms()

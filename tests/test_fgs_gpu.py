@@ -85,6 +85,53 @@ def test_collect_then_splice_matches_reference(gpu, big, monkeypatch):
     al.close()
 
 
+def test_rooms_stream_votes_and_splice_equal_the_reference(gpu):
+    """BASELINE.json configs[4] in small (tests/golden/fgs_splice_rooms.npz, written by the compiled
+    reference): 2 000 frames of rooms-v1 at 320x240 -> 80 fragments -> 16 merges.  Collect on the GPU gives
+    the reference's fragments; the batched extract_all + rmx_kpm_cell_pairs give the reference's vote for
+    every one of the 3 160 initial pairs (kpm.hpp:371-393); fgs::splice (fgs.hpp:187-213: sixteen rounds
+    of select_match / splice_single / match_partial) ends in the reference's canvases and positions."""
+    import torch
+
+    from remap_amd import splice as S
+
+    g = np.load(os.path.join(G, "fgs_splice_rooms.npz"))
+    n, w, h, rooms, dens, seed = g["gen"].tolist()
+    frames, _, _ = rooms_v1(n, width=w, height=h, n_rooms=rooms, dens=dens, seed=seed)
+    al = Aligner(w, h, kmax=2048)
+    d = torch.from_numpy(frames).cuda()
+    out = al.align(d, blit=True)
+    assert out["nfrag"] == int(g["ncollected"]) and np.array_equal(out["frag"].cpu().numpy(), g["collected_frag"])
+    frags = al.fragments(d, out)
+    assert [list(f.dims) for f in frags] == g["collected_dims"].tolist()
+    # the vote matrix of match_all
+    ctxs = {}
+
+    def ctx_cache(key):
+        if key not in ctxs:
+            cw, ch, kmax = (16, 8, S.CELL_CTX_KMAX) if key == "any" else key
+            ctxs[key] = L.Context(cw, ch, grid=(1, 1), overlap=0, kmax=kmax)
+        return ctxs[key]
+
+    snips = S._extract_all(ctx_cache, frags)
+    assert [s.k for s in snips] == g["kcounts"].tolist()
+    pairs = [(i, j) for i in range(len(snips)) for j in range(i + 1, len(snips))]
+    votes = ctx_cache("any").kpm_cell_pairs([s.table for s in snips], [s.k for s in snips], [s.mask for s in snips],
+                                            [s.fragment.dims for s in snips], pairs, S.CELL)
+    got = np.stack([votes["dx"] * votes["valid"], votes["dy"] * votes["valid"], votes["count"] * votes["valid"], votes["valid"]], axis=1)
+    assert np.array_equal(got.astype(np.int64), g["votes"].astype(np.int64))
+    for c in ctxs.values():
+        c.close()
+    res = splice(frags)
+    assert len(res) == int(g["nfrag"]) and int(g["ncollected"]) - len(res) == 16
+    for k, f in enumerate(res):
+        assert list(f.dims) == g["dims"][k].tolist(), k
+        assert poly_sum(f.canvas.cpu().numpy().view(np.uint16)) == int(g["canvas_sum"][k]), k
+        for no, p in f.frames:
+            assert int(g["frag"][no]) == k and list(p) == g["pos"][no].tolist(), (k, no)
+    al.close()
+
+
 def _collect_one(frames, w, h):
     """one fragment out of a frame run: device Fragment + the oracle's canvas and positions"""
     import torch

@@ -179,6 +179,49 @@ def test_fgs_input_is_reproducible():
     assert int(o["frag"].max()) + 1 == int(g["ncollected"])
 
 
+def test_rooms_stream_collect_and_votes():
+    """tests/golden/fgs_splice_rooms.npz (configs[4] in small, written by the reference: 80 fragments, 16
+    merges): the oracle's collect gives the reference's fragments, and its cellular match the reference's
+    votes — all 16 valid pairs and a sample of the 3 144 others."""
+    from remap_amd.synth import rooms_v1
+
+    g = np.load(os.path.join(G, "fgs_splice_rooms.npz"))
+    n, w, h, rooms, dens, seed = g["gen"].tolist()
+    fr, _, _ = rooms_v1(n, width=w, height=h, n_rooms=rooms, dens=dens, seed=seed)
+    assert hashlib.sha256(np.ascontiguousarray(fr).tobytes()).digest() == g["input_sha256"].tobytes()
+    o = O.orc_frc(fr)
+    assert np.array_equal(o["frag"], g["collected_frag"]) and int(g["ncollected"]) == 80 and int(g["nfrag"]) == 64
+    nf = int(g["ncollected"])
+    pairs = [(i, j) for i in range(nf) for j in range(i + 1, nf)]
+    valid = np.nonzero(g["votes"][:, 3])[0]
+    assert len(valid) == 16
+    rng = np.random.default_rng(5)
+    sample = sorted(set(valid.tolist()) | set(rng.choice(len(pairs), 60, replace=False).tolist()))
+    tabs = {}
+
+    def table(f):
+        if f not in tabs:
+            idx = np.nonzero(o["frag"] == f)[0]
+            cw, ch, zx, zy = O.orc_fgm_extent(o["pos"][idx], w, h)
+            assert [cw, ch] == g["collected_dims"][f].tolist()
+            can = np.zeros((ch, cw, 16), np.uint16)
+            for i in idx:
+                O.orc_fgm_blit(can, (zx, zy), fr[i], o["pos"][i])
+            img, mask = O.orc_fgm_blend(can)
+            desc = O.orc_kpe(img, 1, 1, 0)[1]
+            assert len(desc) == int(g["kcounts"][f])
+            tabs[f] = (mask, desc)
+        return tabs[f]
+
+    for k in sample:
+        i, j = pairs[k]
+        m, v = O.orc_kpm_cell(table(i)[1], table(i)[0], table(j)[1], table(j)[0].shape)
+        want = g["votes"][k]
+        assert int(m) == int(want[3]), (i, j)
+        if m:
+            assert (int(v["dx"]), int(v["dy"]), int(v["count"])) == tuple(int(x) for x in want[:3]), (i, j)
+
+
 def test_ful_fragment_files():
     """remap_amd.ful pack/unpack against files the reference's ful::write produced."""
     from remap_amd import ful

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # usage (on the GPU box): bash tools/profile_round.sh <tag>     e.g. r02_a
-# bench line, bench line of the dense stream, rocprofv3 --kernel-trace --stats of the same bench
-# command, PMC passes of kpe_main / kpe_finish -> gpurun_out/prof_<tag>/ (copy what is to be judged
+# bench line (with the other workloads as sub-records), rocprofv3 --kernel-trace --stats of the same bench
+# command (without the sub-records), PMC passes of the extraction kernel -> gpurun_out/prof_<tag>/ (copy what is to be judged
 # into profiles/).
 set -e
 TAG=$1
@@ -10,13 +10,12 @@ OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd $R
 python3 bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
-python3 bench.py --steps 10 --warmup 2 --dens 40 --no-cpu > $OUT/${TAG}_bench_dense.json 2>> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err || tail -5 $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-workloads > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err || tail -5 $OUT/rocprof.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 cd $R
 bash tools/pmc_kpe.sh $TAG > $OUT/pmc.log 2>&1 || tail -5 $OUT/pmc.log
-python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_mf $OUT/${TAG}_pmc_kpe_mf.json > /dev/null
+python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_bs $OUT/${TAG}_pmc_kpe_bs.json > /dev/null
 rm -rf $OUT/stats gpurun_out/pmc_$TAG
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
