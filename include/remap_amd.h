@@ -208,6 +208,15 @@ int rmx_fgm_blit_batch(rmx_ctx* ctx, const uint8_t* frames, const int32_t* pos,
                        uint16_t* canvas, uint32_t canvas_w, uint32_t canvas_h,
                        int32_t zero_x, int32_t zero_y);
 
+/* The same for a canvas that holds no counts yet and has NOT been initialised: every dot of the canvas is
+ * written (the sums of the batch, zeros where no frame lies), none is read — what a caller needs who has
+ * just allocated the canvases of a block: no memset, half the canvas traffic.  n <= 65 535 frames (a
+ * longer batch is cut into launches that add to each other: RMX_ERR_ARG).  No counterpart in the
+ * reference, whose fragment grows its zero-initialised std::vector (fgm.hpp:190-233). */
+int rmx_fgm_blit_fresh(rmx_ctx* ctx, const uint8_t* frames, const int32_t* pos, const uint32_t* frag_id,
+                       uint32_t fragment, uint32_t n, uint16_t* canvas, uint32_t canvas_w, uint32_t canvas_h,
+                       int32_t zero_x, int32_t zero_y);
+
 /* fgm::fragment::ensure/extend/get_step (fgm.hpp:190-233) in closed form: the final
  * canvas of a fragment whose first blit is at (0,0) is the minimal box, grown from the
  * initial step-sized canvas in whole multiples of `step` (= frame dims) on each side, that

@@ -208,6 +208,8 @@ struct BlitParams {
   uint32_t* col_cnt;  // groups_x + 1: counts, then exclusive offsets (in place)
   uint32_t* col_cur;  // groups_x fill cursors
   uint4* col_list;    // (frame, canvas x, canvas y, -) records, <= n * (W / 256 + 2); nullptr: a short batch, not binned
+  uint32_t fresh;     // the canvas holds no counts yet and need not be initialised: every dot is WRITTEN (first fold of a
+                      // tile without reading, tiles no frame touches write zeros) — no memset, no read of the canvas
 };
 
 constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
@@ -316,8 +318,10 @@ template <int R>
 struct BlitCounters {
   uint32_t nib[R][2], byt[R][4];
   uint32_t in_nib, in_byt;  // frames counted since the last fold (uniform)
+  bool wrote;               // this tile's dots have been stored once (uniform)
 
   __device__ __forceinline__ void clear() {
+    wrote = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       nib[r][0] = nib[r][1] = 0;
@@ -332,7 +336,8 @@ struct BlitCounters {
       const int Y = Y0 + r;
       if (Y < (int)p.ch && X < (int)p.cw) {
         uint4* dst = reinterpret_cast<uint4*>(p.canvas + ((size_t)Y * p.cw + (size_t)X) * 8);
-        uint4 a = dst[0], c = dst[1];
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (!p.fresh || wrote) a = dst[0], c = dst[1];
         // dword k of a dot = bins 2k (low half) and 2k+1 (high half); byt[r][0/1] hold the even/odd
         // colours 0..7, byt[r][2/3] those of 8..15, one byte per colour pair k
         const uint32_t e0 = byt[r][0], o0 = byt[r][1], e1 = byt[r][2], o1 = byt[r][3];
@@ -350,6 +355,7 @@ struct BlitCounters {
       byt[r][0] = byt[r][1] = byt[r][2] = byt[r][3] = 0;
     }
     in_byt = 0;
+    wrote = true;
   }
   __device__ __forceinline__ void fold_nibbles(const BlitParams& p, int X, int Y0) {
 #pragma unroll
@@ -369,7 +375,7 @@ struct BlitCounters {
   }
   __device__ __forceinline__ void finish(const BlitParams& p, int X, int Y0) {
     if (in_nib) fold_nibbles(p, X, Y0);
-    if (in_byt) fold_canvas(p, X, Y0);
+    if (in_byt || (p.fresh && !wrote)) fold_canvas(p, X, Y0);
   }
 };
 

@@ -37,6 +37,7 @@ SYMBOLS = [
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
     "rmx_debug_umap_order",
     "rmx_debug_kpe_scratch",
+    "rmx_fgm_blit_fresh",
 ]
 
 
@@ -111,6 +112,7 @@ def load():
     lib.rmx_frc_apply_blocks.argtypes = [vp, vp, u32, u32, vp, vp, u32]
     lib.rmx_frc_finish.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_fgm_blit_batch.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32, i32, i32]
+    lib.rmx_fgm_blit_fresh.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32, i32, i32]
     lib.rmx_fgm_extent.argtypes = [vp, u32, u32, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(i32),
                                    C.POINTER(i32)]
     lib.rmx_fgm_merge.argtypes = [vp, vp, u32, u32, vp, u32, u32, i32, i32]
@@ -405,12 +407,13 @@ class Context:
         self._chk(rc, "rmx_fgm_extent")
         return cw.value, ch.value, zx.value, zy.value
 
-    def fgm_blit(self, frames, pos, canvas, zero, frag_id=None, fragment=0):
+    def fgm_blit(self, frames, pos, canvas, zero, frag_id=None, fragment=0, fresh=False):
+        """fresh: the canvas is uninitialised memory and receives every dot (rmx_fgm_blit_fresh)"""
         ch, cw = canvas.shape[0], canvas.shape[1]
         n = frames.shape[0]
-        self._chk(self.lib.rmx_fgm_blit_batch(self.h, frames.data_ptr(), pos.data_ptr(),
-                                              frag_id.data_ptr() if frag_id is not None else None, fragment, n,
-                                              canvas.data_ptr(), cw, ch, zero[0], zero[1]), "rmx_fgm_blit_batch")
+        fn = self.lib.rmx_fgm_blit_fresh if fresh else self.lib.rmx_fgm_blit_batch
+        self._chk(fn(self.h, frames.data_ptr(), pos.data_ptr(), frag_id.data_ptr() if frag_id is not None else None, fragment, n,
+                     canvas.data_ptr(), cw, ch, zero[0], zero[1]), "rmx_fgm_blit_fresh" if fresh else "rmx_fgm_blit_batch")
 
     def fgm_merge(self, dst, src, off):
         self._chk(self.lib.rmx_fgm_merge(self.h, dst.data_ptr(), dst.shape[1], dst.shape[0], src.data_ptr(),

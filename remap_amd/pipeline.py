@@ -377,7 +377,9 @@ class Aligner:
             self._bufs["canvas_flat"] = flat
         if self.blit_gate is not None:  # (AlignerPipe: the blit kernels wait for the other lane's extraction)
             self.blit_gate()
-        flat.zero_()
+        # canvases without frames of this rank (and blocks too long for one launch) are zeroed; the others are
+        # written in full by the blit itself (rmx_fgm_blit_fresh: no memset, the canvas is not read)
+        fresh = (hi - lo) <= 65535
         stacked = [flat[int(base[c]) * 16:int(base[c + 1]) * 16].view(int(heights[c]), int(wtot[c]), 16) for c in range(len(heights))]
         # this rank's frames: position inside the stacked canvas of their class, and the class
         run_of = np.searchsorted(starts, np.arange(lo, hi), side="right") - 1
@@ -387,8 +389,14 @@ class Aligner:
         adj[:, 2] = cls_of[run_of]
         dev = t.from_numpy(adj).to(self.ctx.device)
         apos, acls = dev[:, :2].contiguous(), dev[:, 2].contiguous()
-        for c in np.unique(adj[:, 2]):
-            self.ctx.fgm_blit(frames, apos, stacked[int(c)], (0, 0), frag_id=acls, fragment=int(c))
+        mine = set(int(c) for c in np.unique(adj[:, 2]))
+        if not fresh:
+            flat.zero_()
+        for c in range(len(heights)):
+            if c in mine:
+                self.ctx.fgm_blit(frames, apos, stacked[c], (0, 0), frag_id=acls, fragment=c, fresh=fresh)
+            elif fresh:
+                stacked[c].zero_()
         canvases = {}
         for i, fid in enumerate(fids):
             c = int(cls_of[i])

@@ -174,6 +174,32 @@ def test_blit_odd_width(gpu):
     ctx.close()
 
 
+def test_blit_into_uninitialised_canvas(gpu):
+    """rmx_fgm_blit_fresh: the canvas starts as garbage and comes out as the oracle's — dots no frame touches
+    included — for wide frames (LDS-DMA kernel), narrow ones, a frame filter, and more than 255 frames on
+    one tile (a tile's second fold must add to its first)."""
+    import torch
+
+    rng = np.random.default_rng(12)
+    for (W, H, n, spread) in [(320, 240, 40, 400), (32, 16, 30, 60), (128, 64, 700, 6)]:
+        frames = rng.integers(0, 16, size=(n, H, W), dtype=np.uint8)
+        pos = np.cumsum(rng.integers(-spread, spread + 1, size=(n, 2)), axis=0).astype(np.int32)
+        pos[0] = 0
+        keep = (rng.random(n) < 0.7).astype(np.uint32)
+        keep[0] = 1
+        ctx = L.Context(W, H, grid=(1, 1), overlap=0, kmax=64)
+        cw, ch, zx, zy = ctx.fgm_extent(pos)
+        want = np.zeros((ch, cw, 16), np.uint16)
+        for i in range(n):
+            if keep[i]:
+                O.orc_fgm_blit(want, (zx, zy), frames[i], pos[i])
+        canvas = torch.full((ch, cw, 16), 0x5555, dtype=torch.int16, device="cuda")
+        ctx.fgm_blit(torch.from_numpy(frames).cuda(), torch.from_numpy(pos).cuda(), canvas, (zx, zy),
+                     frag_id=torch.from_numpy(keep).cuda(), fragment=1, fresh=True)
+        assert np.array_equal(canvas.cpu().numpy().view(np.uint16), want), (W, H)
+        ctx.close()
+
+
 def test_sharded_blit_sums_to_the_whole_canvas(gpu):
     # two "ranks" blit their halves into sub-canvases; adding them at their offsets inside the
     # global box (uint16 wraparound) must give the single-rank canvas (SURVEY.md §8e)
