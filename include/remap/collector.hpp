@@ -37,10 +37,20 @@ inline void add_row(Grid& g, rmx_desc const& d, std::index_sequence<I...>) {
   ((d.region_mask >> I & 1 ? g.add(c, p, std::index_sequence<I>{}) : void()), ...);
 }
 template <typename Grid>
+inline void fill_grid(Grid& g, void const* rows, std::uint32_t n) {
+  auto const* r = static_cast<rmx_desc const*>(rows);
+  for (std::uint32_t i = 0; i < n; ++i) add_row(g, r[i], std::make_index_sequence<Grid::region_count>{});
+}
+template <typename Grid>
 inline Grid table_to_grid(rmx_desc const* rows, std::uint32_t n, typename Grid::allocator_type const& a) {
   Grid g{a};
-  for (std::uint32_t i = 0; i < n; ++i) add_row(g, rows[i], std::make_index_sequence<Grid::region_count>{});
+  fill_grid(g, rows, n);
   return g;
+}
+// ... the same, built when a region is first looked at (rows must stay valid until then)
+template <typename Grid>
+inline Grid table_to_grid_deferred(rmx_desc const* rows, std::uint32_t n, typename Grid::allocator_type const& a) {
+  return Grid{a, &fill_grid<Grid>, rows, n};
 }
 
 // kpr::grid -> rmx_desc table in scan order (x, then y) with region masks.
@@ -241,8 +251,10 @@ public:
     remap::detail::phase_clock clk;
     while (feed.has_more()) {
       clk.mark(nullptr);
-      // ---- drain one block of the feed into host arenas, stage it into HBM ----
-      all::memory_pool pool;
+      // ---- drain one block of the feed into the host arena (reused block after block: its pages are
+      // touched once), stage it into HBM ----
+      all::memory_pool& pool = feed_pool_;
+      pool.reset();
       std::vector<frame_type> block;
       while (feed.has_more() && block.size() < block_frames) block.push_back(feed.produce(pixel_alloc_t{pool}));
       const std::uint32_t n = std::uint32_t(block.size());
@@ -337,41 +349,25 @@ public:
         pk_median = nic::detail::compress_device(ctx_, median_.get<std::uint8_t>(), n, std::uint32_t(area));
       }
       clk.mark("codec");
-      // ---- the per-frame host objects the callbacks borrow (median image, keypoint grid): built
-      // by worker threads, each out of its own arena; the callbacks below stay on this thread,
-      // once per frame in frame order (frc.hpp:119).  One thread: 22 us per frame, the largest
-      // share of a host-bound collect ----
-      const unsigned workers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
-      std::vector<all::memory_pool> arenas(workers);
+      // ---- the per-frame host objects the callbacks borrow (median image, keypoint grid).  Both are made on
+      // demand: the median is a view on the page-locked block that came back from the device, the grid
+      // holds its descriptor rows and builds its maps when a region is first opened — a callback that
+      // only counts frames (main.cpp:139-149) costs nothing per frame; one that reads them pays what the
+      // eager construction cost (22 us per frame on one thread), in the callback ----
+      all::memory_pool arena;
       std::vector<std::optional<image_type>> medians(n);
       std::vector<std::optional<grid_type>> grids(n);
       {
-        std::vector<std::exception_ptr> failed(workers);
-        // (the staging buffers are thread_local: the workers get this thread's pointers)
-        const std::uint8_t* med_src = h_med_.template get<std::uint8_t>();
+        const auto* med_src = reinterpret_cast<cpl::nat_cc const*>(h_med_.template get<std::uint8_t>());
         const auto* tab_src = h_tab_.data();
-        const auto* k_src = h_k_.data();
-        auto prepare = [&, med_src, tab_src, k_src](unsigned w) {
-          try {
-            for (std::uint32_t t = w; t < n; t += workers) {
-              medians[t].emplace(dim_, pixel_alloc_t{arenas[w]});
-              std::memcpy(medians[t]->data(), med_src + t * area, area);
-              if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
-              grids[t].emplace(remap::detail::table_to_grid<grid_type>(tab_src + std::size_t(t) * tstride, k_src[t],
-                                                                       allocator_t<char>{arenas[w]}));
-            }
-          } catch (...) {
-            failed[w] = std::current_exception();
-          }
-        };
-        std::vector<std::thread> pool_threads;
-        for (unsigned w = 1; w < workers; ++w) pool_threads.emplace_back(prepare, w);
-        prepare(0);
-        for (auto& th : pool_threads) th.join();
-        for (auto& e : failed)
-          if (e) std::rethrow_exception(e);
+        for (std::uint32_t t = 0; t < n; ++t) {
+          medians[t].emplace(image_type::view(dim_, med_src + std::size_t(t) * area, pixel_alloc_t{arena}));
+          if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
+          grids[t].emplace(remap::detail::table_to_grid_deferred<grid_type>(tab_src + std::size_t(t) * tstride, h_k_[t],
+                                                                            allocator_t<char>{arena}));
+        }
       }
-      clk.mark("host objects (medians, grids; worker threads)");
+      clk.mark("host objects (median views, deferred grids)");
       // ---- device blit of the block, fragment by fragment (frc.hpp:129-135) ----
       for (std::uint32_t i = 0; i < n;) {
         std::uint32_t j = i;
@@ -463,6 +459,7 @@ private:
   rmx_ctx* ctx_;
   std::uint32_t kmax_{kmax};
   bool exact_callbacks_{false};
+  all::memory_pool feed_pool_;  // the frames of the block in flight (feed.produce allocates from it)
   remap::device_buffer frames_, median_, desc_, kcount_, dxdy_, matched_, pos_, frag_, halo_;
   std::vector<std::int32_t> h_pos_;
   std::vector<std::uint32_t> h_frag_, h_k_;

@@ -143,7 +143,11 @@ using dimensions_t = cdt::dimensions<size_type>;
 using limits_t = cdt::limits<size_type>;
 using region_t = cdt::region<size_type>;
 
-// Row-major dense matrix over std::vector (mrl.hpp:14-157).
+// Row-major dense matrix over std::vector (mrl.hpp:14-157).  A matrix may BORROW its cells (view()): a
+// read-only window on memory someone else owns — frc::collector hands every callback the frame's median
+// image (frc.hpp:119) straight out of the page-locked buffer the block came back in, instead of copying
+// 76 800 bytes per frame for a callback that, in main.cpp, does not look at it.  Any write access (and any
+// copy) turns the view into an owning matrix first.
 template <typename T, typename Alloc = std::allocator<T>>
 class matrix {
 public:
@@ -156,25 +160,48 @@ public:
   matrix(dimensions_t d, T const& v, allocator_type const& a) : dim_{d}, cells_{a} { cells_.resize(d.area(), v); }
   matrix(dimensions_t d) : matrix(d, allocator_type{}) {}
   matrix(dimensions_t d, T const& v) : matrix(d, v, allocator_type{}) {}
+  // borrowed cells: valid while `cells` is (the collector's callbacks: for the duration of the call)
+  static matrix view(dimensions_t d, T const* cells, allocator_type const& a = allocator_type{}) {
+    matrix m{a};
+    m.dim_ = d;
+    m.borrowed_ = cells;
+    return m;
+  }
+  matrix(matrix const& o) : dim_{o.dim_}, cells_{o.cells_.get_allocator()} { cells_.assign(o.data(), o.end()); }
+  matrix(matrix&& o) noexcept : dim_{o.dim_}, cells_{std::move(o.cells_)}, borrowed_{o.borrowed_} { o.dim_ = {}, o.borrowed_ = nullptr; }
+  matrix& operator=(matrix const& o) {
+    if (this != &o) {
+      dim_ = o.dim_;
+      cells_.assign(o.data(), o.end());
+      borrowed_ = nullptr;
+    }
+    return *this;
+  }
+  matrix& operator=(matrix&& o) noexcept {
+    dim_ = o.dim_, cells_ = std::move(o.cells_), borrowed_ = o.borrowed_;
+    o.dim_ = {}, o.borrowed_ = nullptr;
+    return *this;
+  }
 
-  T& operator[](size_type i) noexcept { return cells_[i]; }
-  T const& operator[](size_type i) const noexcept { return cells_[i]; }
-  T* data() noexcept { return cells_.data(); }
-  T const* data() const noexcept { return cells_.data(); }
-  T* end() noexcept { return cells_.data() + cells_.size(); }
-  T const* end() const noexcept { return cells_.data() + cells_.size(); }
+  T& operator[](size_type i) { return own()[i]; }
+  T const& operator[](size_type i) const noexcept { return data()[i]; }
+  T* data() { return own(); }
+  T const* data() const noexcept { return borrowed_ ? borrowed_ : cells_.data(); }
+  T* end() { return own() + size(); }
+  T const* end() const noexcept { return data() + size(); }
   size_type width() const noexcept { return dim_.width_; }
   size_type height() const noexcept { return dim_.height_; }
-  size_type size() const noexcept { return cells_.size(); }
+  size_type size() const noexcept { return borrowed_ ? dim_.area() : cells_.size(); }
   dimensions_t const& dimensions() const noexcept { return dim_; }
   allocator_type get_allocator() const noexcept { return cells_.get_allocator(); }
+  bool is_view() const noexcept { return borrowed_ != nullptr; }
 
   template <typename Fn>
     requires std::invocable<Fn, T const&>
   auto map(Fn fn) const {
     using R = std::invoke_result_t<Fn, T const&>;
     matrix<R> out{dim_};
-    std::transform(cells_.begin(), cells_.end(), out.data(), fn);
+    std::transform(data(), end(), out.data(), fn);
     return out;
   }
 
@@ -194,8 +221,16 @@ public:
   }
 
 private:
+  T* own() {
+    if (borrowed_) {
+      cells_.assign(borrowed_, borrowed_ + dim_.area());
+      borrowed_ = nullptr;
+    }
+    return cells_.data();
+  }
   dimensions_t dim_{};
   std::vector<T, Alloc> cells_;
+  T const* borrowed_{nullptr};
 };
 
 }  // namespace mrl
@@ -318,6 +353,19 @@ public:
     return blocks_.back().first + at;
   }
   std::size_t total_used() const noexcept { return total_used_; }
+  // forget what was handed out, keep the memory: one block as large as everything that was reserved
+  // (pages already touched stay mapped: a pool reused block after block takes no page faults)
+  void reset() {
+    if (blocks_.size() > 1) {
+      const std::size_t all = total_;
+      for (auto& b : blocks_) std::free(b.first);
+      blocks_.clear();
+      total_ = 0;
+      grow(all);
+    }
+    used_ = 0;
+    total_used_ = 0;
+  }
   void swap(memory_pool& o) noexcept {
     blocks_.swap(o.blocks_);
     std::swap(used_, o.used_);

@@ -76,23 +76,63 @@ public:
   using allocator_type = Alloc;
   using region_type = region<allocator_type>;
   using regions_t = std::span<region_type const, region_count>;
+  // A grid may be handed a SOURCE instead of keypoints: `fill(grid, source, count)` adds them the first
+  // time a region is looked at.  frc::collector gives every callback a grid (frc.hpp:119); most
+  // callbacks — main.cpp's counts frames — never open it, and building eight unordered_maps per frame
+  // was the largest share of a host-bound collect.  The source must outlive the grid or its first
+  // use, whichever comes first; copies are made of the materialised grid.
+  using fill_fn = void (*)(grid&, void const*, std::uint32_t);
 
   explicit grid(allocator_type const& a) : grid(a, std::make_index_sequence<region_count>{}) {}
   grid() : grid(allocator_type{}) {}
+  grid(allocator_type const& a, fill_fn fill, void const* source, std::uint32_t count)
+      : grid(a, std::make_index_sequence<region_count>{}) {
+    fill_ = fill, source_ = source, count_ = count;
+  }
+  grid(grid const& o) : grid(o.materialised(), 0) {}  // (a copy may outlive the source: it is made of the keypoints)
+  grid(grid&& o) : grid(std::move(o), 0) {}            // (a move keeps the deferred state: same lifetime contract)
+  grid& operator=(grid o) {
+    for (std::size_t i = 0; i < region_count; ++i) cells_[i] = std::move(o.cells_[i]);
+    fill_ = o.fill_, source_ = o.source_, count_ = o.count_;
+    return *this;
+  }
 
   // add a keypoint to every region named in the index list (region index = height*col + row)
   template <std::size_t... I>
   void add(code const& key, mrl::point_t p, std::index_sequence<I...>) {
     (cells_[I].add(key, p), ...);
   }
-  regions_t regions() const noexcept { return regions_t{cells_}; }
-  region_type& operator[](std::size_t i) noexcept { return cells_[i]; }
-  region_type const& operator[](std::size_t i) const noexcept { return cells_[i]; }
+  regions_t regions() const noexcept { return regions_t{materialised().cells_}; }
+  region_type& operator[](std::size_t i) noexcept { return materialised_mut().cells_[i]; }
+  region_type const& operator[](std::size_t i) const noexcept { return materialised().cells_[i]; }
+  bool deferred() const noexcept { return fill_ != nullptr; }
 
 private:
   template <std::size_t... I>
   grid(allocator_type const& a, std::index_sequence<I...>) : cells_{((void)I, region_type{a})...} {}
+  grid(grid const& src, int) : grid(src.cells_[0].get_allocator(), std::make_index_sequence<region_count>{}) {
+    for (std::size_t i = 0; i < region_count; ++i) cells_[i] = src.cells_[i];
+  }
+  grid(grid&& src, int) : grid(src.cells_[0].get_allocator(), std::make_index_sequence<region_count>{}) {
+    for (std::size_t i = 0; i < region_count; ++i) cells_[i] = std::move(src.cells_[i]);
+    fill_ = src.fill_, source_ = src.source_, count_ = src.count_;
+    src.fill_ = nullptr;
+  }
+  grid& materialised_mut() const {
+    grid& self = const_cast<grid&>(*this);  // (the deferred state is a cache of what the grid already "holds")
+    if (fill_) {
+      fill_fn f = fill_;
+      self.fill_ = nullptr;
+      f(self, source_, count_);
+    }
+    return self;
+  }
+  grid const& materialised() const { return materialised_mut(); }
+
   region_type cells_[region_count];
+  fill_fn fill_{nullptr};
+  void const* source_{nullptr};
+  std::uint32_t count_{0};
 };
 
 template <typename G>

@@ -14,7 +14,10 @@
 
 #include <iterator>
 #include <list>
+#include <map>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "collector.hpp"
@@ -45,38 +48,53 @@ struct delta {
   snippet_iterator_t other_;
 };
 
+// a snippet's descriptor table: rows inside a block that may be shared with the other snippets of one
+// batched extraction (extract_all); the block lives as long as any of its tables
+struct table_rows {
+  std::shared_ptr<remap::device_buffer> block_;
+  std::size_t first_row_{0};
+  template <typename T>
+  T* get() const noexcept {
+    return block_ ? reinterpret_cast<T*>(block_->template get<rmx_desc>() + first_row_) : nullptr;
+  }
+};
+
 struct snippet {
   fgm::fragment fragment_;
-  remap::device_buffer mask_;   // dim.area() bytes, non-zero where the canvas has content
-  remap::device_buffer table_;  // count_ rmx_desc rows (stride: the kmax it was extracted with)
+  remap::device_buffer mask_;  // dim.area() bytes, non-zero where the canvas has content
+  table_rows table_;           // count_ rmx_desc rows (stride: the kmax it was extracted with)
   std::uint32_t count_{0};
   std::list<delta> edges_;
 };
 
-// fgs.hpp:80-89 — blend the canvas, extract keypoints of the blended image (one region)
-inline snippet extract_single(fgm::fragment&& fragment) {
-  snippet s{std::move(fragment), {}, {}, 0, {}};
-  const auto dim = s.fragment_.dimensions();
-  const std::uint32_t w = std::uint32_t(dim.width_), h = std::uint32_t(dim.height_);
+// fgs.hpp:80-103 — blend the canvases, extract the keypoints of the blended images (one region each).
+// The reference runs extract_single over the fragments under std::execution::par; here all fragments of
+// one canvas size go through ONE rmx_kpe_batch launch and one status / count read-back (a stream with
+// hundreds of fragments otherwise pays a device round trip per fragment before the first pair is scored).
+inline void extract_group(std::vector<snippet*> const& group, std::uint32_t w, std::uint32_t h) {
+  const std::uint32_t n = std::uint32_t(group.size());
+  const std::size_t area = std::size_t(w) * h;
   rmx_ctx* c = remap::context_cache::get(w, h, 1, 1, 0, snippet_kmax);
-  const std::size_t area = dim.area();
-  remap::device_buffer image{c, area}, median{c, area}, kcount{c, 16};
-  s.mask_ = remap::device_buffer{c, area};
-  if (s.fragment_.device_canvas()) {
-    remap::check(rmx_fgm_blend(c, s.fragment_.device_canvas(), w, h, image.get<std::uint8_t>(), s.mask_.get<std::uint8_t>()),
-                 c, "rmx_fgm_blend");
-  } else {
-    remap::check(rmx_memset(c, image.get(), 0, area), c, "rmx_memset");
-    remap::check(rmx_memset(c, s.mask_.get(), 0, area), c, "rmx_memset");
+  remap::device_buffer images{c, n * area}, medians{c, n * area}, kcount{c, std::size_t(n) * 4 + 16};
+  for (std::uint32_t i = 0; i < n; ++i) {
+    snippet& s = *group[i];
+    s.mask_ = remap::device_buffer{c, area};
+    if (s.fragment_.device_canvas()) {
+      remap::check(rmx_fgm_blend(c, s.fragment_.device_canvas(), w, h, images.get<std::uint8_t>() + i * area, s.mask_.get<std::uint8_t>()),
+                   c, "rmx_fgm_blend");
+    } else {
+      remap::check(rmx_memset(c, images.get<std::uint8_t>() + i * area, 0, area), c, "rmx_memset");
+      remap::check(rmx_memset(c, s.mask_.get(), 0, area), c, "rmx_memset");
+    }
   }
   for (std::uint32_t kmax = snippet_kmax;;) {
-    s.table_ = remap::device_buffer{c, kmax * sizeof(rmx_desc)};
-    remap::check(rmx_kpe_batch(c, image.get<std::uint8_t>(), 1, median.get<std::uint8_t>(), s.table_.get<rmx_desc>(),
+    auto block = std::make_shared<remap::device_buffer>(c, std::size_t(n) * kmax * sizeof(rmx_desc));
+    remap::check(rmx_kpe_batch(c, images.get<std::uint8_t>(), n, medians.get<std::uint8_t>(), block->get<rmx_desc>(),
                                kcount.get<std::uint32_t>()),
                  c, "rmx_kpe_batch");
     std::uint32_t need = 0;
     const int st = rmx_kpe_status(c, &need);
-    if (st == RMX_ERR_KMAX && need <= snippet_kmax_limit) {  // same canvas, larger table
+    if (st == RMX_ERR_KMAX && need <= snippet_kmax_limit) {  // same canvases, larger tables
       while (kmax < need) kmax <<= 1;
       remap::check(rmx_sync(c), c, "rmx_sync");
       c = remap::context_cache::get(w, h, 1, 1, 0, kmax);
@@ -87,9 +105,30 @@ inline snippet extract_single(fgm::fragment&& fragment) {
                                         std::to_string(need) + " keypoints; a descriptor table holds at most " +
                                         std::to_string(snippet_kmax_limit));
     remap::check(st, c, "rmx_kpe_status");
+    std::vector<std::uint32_t> counts(n);
+    remap::check(rmx_download(c, counts.data(), kcount.get(), std::size_t(n) * 4), c, "rmx_download");
+    for (std::uint32_t i = 0; i < n; ++i) {
+      group[i]->table_ = table_rows{block, std::size_t(i) * kmax};
+      group[i]->count_ = counts[i];
+    }
     break;
   }
-  remap::check(rmx_download(c, &s.count_, kcount.get(), 4), c, "rmx_download");
+}
+
+template <typename It>
+void extract_all(It first, It last) {  // snippets whose fragment_ is set
+  std::map<std::pair<std::uint32_t, std::uint32_t>, std::vector<snippet*>> by_size;
+  for (; first != last; ++first) {
+    const auto dim = first->fragment_.dimensions();
+    by_size[{std::uint32_t(dim.width_), std::uint32_t(dim.height_)}].push_back(&*first);
+  }
+  for (auto const& [size, group] : by_size) extract_group(group, size.first, size.second);
+}
+
+inline snippet extract_single(fgm::fragment&& fragment) {  // fgs.hpp:80-89
+  snippet s{std::move(fragment), {}, {}, 0, {}};
+  const auto dim = s.fragment_.dimensions();
+  extract_group({&s}, std::uint32_t(dim.width_), std::uint32_t(dim.height_));
   return s;
 }
 
@@ -145,7 +184,8 @@ template <typename Iter>
 std::vector<fgm::fragment> splice(Iter first, Iter last) {
   using namespace details;
   snippet_list snippets;
-  for (; first != last; ++first) snippets.push_back(extract_single(std::move(*first)));  // extract_all
+  for (; first != last; ++first) snippets.push_back(snippet{std::move(*first), {}, {}, 0, {}});
+  extract_all(snippets.begin(), snippets.end());
   match_all(snippets.begin(), snippets.end());
   for (;;) {
     // select_match (fgs.hpp:142-163): first maximum of the vote count over primary edges

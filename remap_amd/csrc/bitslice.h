@@ -173,6 +173,29 @@ RMX_HD void map_planes(const uint32_t (&v)[4], uint32_t (&o)[4]) {
   o[3] = map_plane<TBL, 3>(v);
 }
 
+// The two tables of the extraction (reference cpl.hpp:163-217): native colour -> luminance rank, and
+// (complemented rank) -> native colour for the way back.  Every output bit is a function of four planes:
+// generically three operations (two halves and a mux); an exhaustive search over two-operation forms
+// (a three-input function of three planes, then one of its result and two planes) found shorter ones for
+// four of the eight bits — 19 operations for both tables instead of 24.  tests/test_host_logic.py checks
+// these against the tables on all sixteen values and, through the medians, against the oracle.
+constexpr uint8_t kRankOfNative[16] = {0, 15, 2, 12, 6, 9, 3, 13, 5, 1, 7, 4, 8, 14, 10, 11};
+constexpr uint8_t kNativeOfRank[16] = {0, 9, 2, 6, 11, 8, 4, 10, 12, 5, 14, 15, 3, 7, 13, 1};
+RMX_HD void rank_planes(const uint32_t (&n)[4], uint32_t (&x)[4]) {
+  constexpr uint64_t T = pack_tbl(kRankOfNative, false);
+  x[0] = map_plane<T, 0>(n);
+  x[1] = map_plane<T, 1>(n);
+  x[2] = map_plane<T, 2>(n);
+  x[3] = bop3<f_tt<216>>(n[0], n[2], n[3]);
+}
+RMX_HD void native_planes_of_inverted_rank(const uint32_t (&nr)[4], uint32_t (&o)[4]) {
+  constexpr uint64_t T = pack_tbl(kNativeOfRank, true);
+  o[0] = bop3<f_tt<208>>(bop3<f_tt<61>>(nr[0], nr[2], nr[3]), nr[1], nr[3]);
+  o[1] = bop3<f_tt<54>>(bop3<f_tt<10>>(nr[0], nr[1], nr[3]), nr[1], nr[2]);
+  o[2] = map_plane<T, 2>(nr);
+  o[3] = bop3<f_tt<150>>(bop3<f_tt<24>>(nr[0], nr[1], nr[2]), nr[2], nr[3]);
+}
+
 // ---- the window -----------------------------------------------------------------------------------------
 // One image row as the selection sees it: rank planes of the pixel itself (c), of its left (l) and right
 // (r) neighbour, and the horizontal count of the most significant bit (hs + 2 hc = l[3] + c[3] + r[3]).

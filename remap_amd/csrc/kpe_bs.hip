@@ -25,10 +25,13 @@
 namespace rmx {
 
 constexpr uint32_t KPE_BS_RA_MAX = 30;  // rows per strip (a multiple of 6; row index: 5 bits of a list entry)
-constexpr uint32_t KPE_BS_LIST = 2048;   // candidates handed out per round
+#ifndef RMX_BS_LIST
+#define RMX_BS_LIST 2048
+#endif
+constexpr uint32_t KPE_BS_LIST = RMX_BS_LIST;  // candidates handed out per round
 
-constexpr uint64_t kBsRankTbl = bs::pack_tbl(kN2O, false);
-constexpr uint64_t kBsNativeOfInvRank = bs::pack_tbl(kO2N, true);
+static_assert(bs::pack_tbl(kN2O, false) == bs::pack_tbl(bs::kRankOfNative, false) && bs::pack_tbl(kO2N, false) == bs::pack_tbl(bs::kNativeOfRank, false),
+              "bitslice.h carries the same tables as common.h");
 
 __device__ __forceinline__ uint32_t from_prev_lane(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);  // wave_shr:1
@@ -52,12 +55,40 @@ __device__ __forceinline__ void bs_make_row(const BsRaw& w, bs::Row& R) {
   const uint32_t a[4] = {w.a[0], w.a[1], w.a[2], w.a[3]}, b[4] = {w.b[0], w.b[1], w.b[2], w.b[3]};
   uint32_t n[4];
   bs::planes_from_bytes(a, b, n);
-  bs::map_planes<kBsRankTbl>(n, R.c);
+  bs::rank_planes(n, R.c);
+#if defined(RMX_BS_NODPPASM)  /* experiment: the compiler's v_mov_b32_dpp + v_or_b32 (it does not fold wave shifts) */
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     R.l[q] = bs::left_of(R.c[q], from_prev_lane(bs::send_right(R.c[q])));
     R.r[q] = bs::right_of(R.c[q], from_next_lane(bs::send_left(R.c[q])));
   }
+#else
+  // neighbour planes: what the neighbouring lane sends is OR-ed in by the DPP operand of the v_or itself
+  // (eight v_mov_b32_dpp fewer per row).  A DPP source written by the instruction before needs two wait
+  // states, and the compiler does not look into an asm block: all sent words are computed first, one
+  // s_nop 1 in front covers whichever of them came last.
+  uint32_t sr[4], sl[4], ul[4], ur[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    sr[q] = bs::send_right(R.c[q]);
+    sl[q] = bs::send_left(R.c[q]);
+    ul[q] = bs::half_shl(R.c[q], 1);
+    ur[q] = bs::half_shr(R.c[q], 1);
+  }
+  asm volatile(
+      "s_nop 1\n\t"
+      "v_or_b32_dpp %0, %8, %16 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %1, %9, %17 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %2, %10, %18 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %3, %11, %19 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %4, %12, %20 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %5, %13, %21 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %6, %14, %22 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_or_b32_dpp %7, %15, %23 wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "=&v"(R.l[0]), "=&v"(R.l[1]), "=&v"(R.l[2]), "=&v"(R.l[3]), "=&v"(R.r[0]), "=&v"(R.r[1]), "=&v"(R.r[2]), "=&v"(R.r[3])
+      : "v"(sr[0]), "v"(sr[1]), "v"(sr[2]), "v"(sr[3]), "v"(sl[0]), "v"(sl[1]), "v"(sl[2]), "v"(sl[3]), "v"(ul[0]), "v"(ul[1]),
+        "v"(ul[2]), "v"(ul[3]), "v"(ur[0]), "v"(ur[1]), "v"(ur[2]), "v"(ur[3]));
+#endif
   bs::row_sums(R);
 }
 
@@ -187,7 +218,7 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 #define RMX_BS_SELECT(A, B, Cn)                                                                            \
   bs::select4of9(A, B, Cn, nr);                                                                            \
   s_c[jj][threadIdx.x] = bs::differs(nr, B.c, valid);                                                      \
-  bs::map_planes<kBsNativeOfInvRank>(nr, nat);                                                             \
+  bs::native_planes_of_inverted_rank(nr, nat);                                                             \
   nat[0] &= valid, nat[1] &= valid, nat[2] &= valid, nat[3] &= valid;                                      \
   bs::bytes_from_planes(nat, oa4, ob4);
 #endif

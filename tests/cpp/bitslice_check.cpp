@@ -17,6 +17,27 @@ constexpr uint64_t kRankTbl = pack_tbl(kN2O, false);
 constexpr uint64_t kNativeOfInvRank = pack_tbl(kO2N, true);
 }  // namespace
 
+// the plane forms of both tables on all sixteen values (bit v of plane q = bit q of value v)
+extern "C" int bs_tables_ok() {
+  uint32_t v[4] = {0xaaaau, 0xccccu, 0xf0f0u, 0xff00u}, x[4], inv[4], o[4];
+  rank_planes(v, x);
+  for (int q = 0; q < 4; ++q) inv[q] = ~x[q];
+  native_planes_of_inverted_rank(inv, o);
+  for (int i = 0; i < 16; ++i) {
+    int r = 0, back = 0;
+    for (int q = 0; q < 4; ++q) r |= ((x[q] >> i) & 1) << q, back |= ((o[q] >> i) & 1) << q;
+    if (r != kN2O[i] || back != i) return 0;
+  }
+  uint32_t g[4];
+  map_planes<kRankTbl>(v, g);  // the generic three-operation form gives the same planes
+  for (int q = 0; q < 4; ++q)
+    if ((g[q] & 0xffffu) != (x[q] & 0xffffu)) return 0;
+  map_planes<kNativeOfInvRank>(inv, g);
+  for (int q = 0; q < 4; ++q)
+    if ((g[q] & 0xffffu) != (o[q] & 0xffffu)) return 0;
+  return 1;
+}
+
 extern "C" int bs_planes_roundtrip(const uint8_t* px32, uint8_t* out32, uint32_t* planes4) {
   uint32_t a[4], b[4], n[4], a2[4], b2[4];
   std::memcpy(a, px32, 16);
@@ -46,7 +67,7 @@ extern "C" int bs_kpe_3x3(const uint8_t* frame, uint32_t W, uint32_t H, uint8_t*
       std::memcpy(a, frame + (size_t)y * W + 16 * c, 16);
       std::memcpy(b, frame + (size_t)rowB((int)y) * W + 16 * c, 16);
       planes_from_bytes(a, b, n);
-      map_planes<kRankTbl>(n, x);
+      rank_planes(n, x);
       std::memcpy(&pl[4 * c], x, 16);
     }
     for (uint32_t c = 0; c < nc; ++c) {
@@ -78,7 +99,7 @@ extern "C" int bs_kpe_3x3(const uint8_t* frame, uint32_t W, uint32_t H, uint8_t*
       uint32_t nr[4], nat[4], a[4], b[4];
       select4of9(rows[(size_t)ym * nc + c], rows[(size_t)y * nc + c], rows[(size_t)yp * nc + c], nr);
       const uint32_t cd = differs(nr, rows[(size_t)y * nc + c].c, valid);
-      map_planes<kNativeOfInvRank>(nr, nat);
+      native_planes_of_inverted_rank(nr, nat);
       for (int q = 0; q < 4; ++q) nat[q] &= valid;
       bytes_from_planes(nat, a, b);
       if (valid & 0xffffu) {

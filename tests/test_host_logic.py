@@ -158,6 +158,7 @@ def test_bitplane_3x3_pass_matches_oracle(tmp_path):
     lib = ctypes.CDLL(str(so))
     lib.bs_planes_roundtrip.argtypes = [ctypes.c_void_p] * 3
     lib.bs_kpe_3x3.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p]
+    assert lib.bs_tables_ok() == 1
     rng = np.random.default_rng(1)
     for _ in range(50):
         px = rng.integers(0, 16, 32, dtype=np.uint8)
