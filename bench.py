@@ -229,6 +229,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=2, help="blocks in flight (AlignerPipe); 1: one stream")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other BASELINE.json workloads (dense, 640x480, rooms)")
+    ap.add_argument("--headline-only", action="store_true", help="only the headline's steps (and the one-lane repeat): no tiers B/C, host-fed "
+                                                                   "rate, copy rates or earlier kernels — for kernel traces of the timed region")
     ap.add_argument("--cpu-frames", type=int, default=10000)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the "
                                                       "multi-rank flow on one GPU")
@@ -349,93 +351,100 @@ def main():
     # per-step totals of the other kernels (kpm_build / kpm_match run several instances each)
     ms_parts = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3
                 for k in ("kpe_table", "kpm_build", "kpm_match")}
-    # the extraction kernels of earlier rounds on this box, untimed part: the two-kernel form (rounds 1-2a:
-    # kpe_main + kpe_finish) and kpe_mf (round 2; a context made with RMX_KPE_BS=0)
-    os.environ["RMX_KPE_PAIR"] = "1"
-    al.align(frames, n_total=n_total)
-    al.ctx.set_timing(True)
-    for _ in range(3):
+    if not args.headline_only:
+        # the extraction kernels of earlier rounds on this box, untimed part: the two-kernel form (rounds 1-2a:
+        # kpe_main + kpe_finish) and kpe_mf (round 2; a context made with RMX_KPE_BS=0)
+        os.environ["RMX_KPE_PAIR"] = "1"
         al.align(frames, n_total=n_total)
-    pair = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3 for k in ("kpe_main", "kpe_finish")}
-    del os.environ["RMX_KPE_PAIR"]
-    al.ctx.set_timing(False)
-    os.environ["RMX_KPE_BS"] = "0"
-    mf = L.Context(W, H, kmax=2048, device=local_rank)
-    del os.environ["RMX_KPE_BS"]
-    mf_out = mf.kpe(frames)
-    mf.set_timing(True)
-    for _ in range(5):
-        mf.kpe(frames, *mf_out)
-    ms_kpe_mf = mf.kernel_ms("kpe_main")
-    mf.close()
-    del mf_out
+        al.ctx.set_timing(True)
+        for _ in range(3):
+            al.align(frames, n_total=n_total)
+        pair = {k: al.ctx.kernel_ms(k) * al.ctx.kernel_launches(k) / 3 for k in ("kpe_main", "kpe_finish")}
+        del os.environ["RMX_KPE_PAIR"]
+        al.ctx.set_timing(False)
+        os.environ["RMX_KPE_BS"] = "0"
+        mf = L.Context(W, H, kmax=2048, device=local_rank)
+        del os.environ["RMX_KPE_BS"]
+        mf_out = mf.kpe(frames)
+        mf.set_timing(True)
+        for _ in range(5):
+            mf.kpe(frames, *mf_out)
+        ms_kpe_mf = mf.kernel_ms("kpe_main")
+        mf.close()
+        del mf_out
 
-    # tier B: + fgm blit into the fragment canvases (reported beside the headline); blocks in
-    # flight as above (AlignerPipe.submit / drain: the host-side stage of block t — positions to
-    # the host, canvas extents — and its blit run beside the alignment of block t + 1)
-    pipe.submit(frames, n_total=n_total, blit=True)
-    pipe.submit(frames, n_total=n_total, blit=True)
-    pipe.drain()
-    barrier()
-    t1 = time.perf_counter()
-    nb = args.steps
-    for _ in range(nb):
+        # tier B: + fgm blit into the fragment canvases (reported beside the headline); blocks in
+        # flight as above (AlignerPipe.submit / drain: the host-side stage of block t — positions to
+        # the host, canvas extents — and its blit run beside the alignment of block t + 1)
         pipe.submit(frames, n_total=n_total, blit=True)
-    pipe.drain()
-    barrier()
-    dtb = time.perf_counter() - t1
+        pipe.submit(frames, n_total=n_total, blit=True)
+        pipe.drain()
+        barrier()
+        t1 = time.perf_counter()
+        nb = args.steps
+        for _ in range(nb):
+            pipe.submit(frames, n_total=n_total, blit=True)
+        pipe.drain()
+        barrier()
+        dtb = time.perf_counter() - t1
 
-    # tier C: + the frame codec main.cpp plugs into collect (nic::compress of image and median)
-    pipe.submit(frames, n_total=n_total, blit=True, compress=True)
-    pipe.submit(frames, n_total=n_total, blit=True, compress=True)
-    pipe.drain()
-    barrier()
-    t3 = time.perf_counter()
-    for _ in range(nb):
+        # tier C: + the frame codec main.cpp plugs into collect (nic::compress of image and median)
         pipe.submit(frames, n_total=n_total, blit=True, compress=True)
-    pipe.drain()
-    barrier()
-    dtc = time.perf_counter() - t3
-    # ... and one block at a time (rounds 1-2e's figures)
-    al.align(frames, n_total=n_total, blit=True)
-    barrier()
-    t1 = time.perf_counter()
-    nb1 = max(1, args.steps // 4)
-    for _ in range(nb1):
+        pipe.submit(frames, n_total=n_total, blit=True, compress=True)
+        pipe.drain()
+        barrier()
+        t3 = time.perf_counter()
+        for _ in range(nb):
+            pipe.submit(frames, n_total=n_total, blit=True, compress=True)
+        pipe.drain()
+        barrier()
+        dtc = time.perf_counter() - t3
+        # ... and one block at a time (rounds 1-2e's figures)
         al.align(frames, n_total=n_total, blit=True)
-    barrier()
-    dtb_one = time.perf_counter() - t1
+        barrier()
+        t1 = time.perf_counter()
+        nb1 = max(1, args.steps // 4)
+        for _ in range(nb1):
+            al.align(frames, n_total=n_total, blit=True)
+        barrier()
+        dtb_one = time.perf_counter() - t1
 
-    # host-fed rate: the same step with the frames coming from pinned host
-    # memory over PCIe every time — reported beside the headline, never as `value`
-    pinned = torch.from_numpy(frames_host).pin_memory()
-    stage = torch.empty_like(frames)
-    stage.copy_(pinned, non_blocking=True)
-    al.align(stage, n_total=n_total)
-    barrier()
-    t2 = time.perf_counter()
-    nh = max(1, args.steps // 4)
-    for _ in range(nh):
+        # host-fed rate: the same step with the frames coming from pinned host
+        # memory over PCIe every time — reported beside the headline, never as `value`
+        pinned = torch.from_numpy(frames_host).pin_memory()
+        stage = torch.empty_like(frames)
         stage.copy_(pinned, non_blocking=True)
         al.align(stage, n_total=n_total)
-    barrier()
-    dth = time.perf_counter() - t2
-    # what a plain device copy of the same footprint reaches on this box (the practical HBM
-    # ceiling next to the 8 TB/s spec figure): read n*W*H + write n*W*H bytes, with the library's
-    # own streaming copy kernel (rmx_copy) and, for reference, torch's device copy
-    def copy_rate(fn):
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        fn()
-        ev0.record()
-        for _ in range(10):
+        barrier()
+        t2 = time.perf_counter()
+        nh = max(1, args.steps // 4)
+        for _ in range(nh):
+            stage.copy_(pinned, non_blocking=True)
+            al.align(stage, n_total=n_total)
+        barrier()
+        dth = time.perf_counter() - t2
+        # what a plain device copy of the same footprint reaches on this box (the practical HBM
+        # ceiling next to the 8 TB/s spec figure): read n*W*H + write n*W*H bytes, with the library's
+        # own streaming copy kernel (rmx_copy) and, for reference, torch's device copy
+        def copy_rate(fn):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fn()
-        ev1.record()
-        torch.cuda.synchronize()
-        return 2.0 * frames.numel() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+            ev0.record()
+            for _ in range(10):
+                fn()
+            ev1.record()
+            torch.cuda.synchronize()
+            return 2.0 * frames.numel() * 10 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
 
-    copy_gbs = copy_rate(lambda: al.ctx.copy(stage, frames))
-    torch_copy_gbs = copy_rate(lambda: stage.copy_(frames))
-    del pinned, stage
+        copy_gbs = copy_rate(lambda: al.ctx.copy(stage, frames))
+        torch_copy_gbs = copy_rate(lambda: stage.copy_(frames))
+        del pinned, stage
+    else:  # (tools/profile_round.sh: the kernel trace of this run holds the headline's launches only)
+        pair = {"kpe_main": 0.0, "kpe_finish": 0.0}
+        ms_kpe_mf = 0.0
+        dtb = dtc = dth = dtb_one = float("inf")
+        nb = nb1 = nh = 1
+        copy_gbs = torch_copy_gbs = None
 
     tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0, dt_one, dtb_one], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
     if dist is not None:
@@ -496,7 +505,7 @@ def main():
                                               "kpe_main_ms": pair["kpe_main"], "kpe_finish_ms": pair["kpe_finish"],
                                               "kpe_main_plus_finish_frac": alg_bytes / ((pair["kpe_main"] + pair["kpe_finish"]) * 1e-3) / 1e9 / HBM_PEAK_GBS
                                               if pair["kpe_main"] > 0 else None},
-                         "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs,
+                         "device_copy_gbs": copy_gbs, "frac_of_device_copy": achieved / copy_gbs if copy_gbs else None,
                          "torch_device_copy_gbs": torch_copy_gbs,
                          "valu_wave_instructions": valu, "valu_wave_instructions_source": pmc_src if valu else None,
                          "algorithmic_bytes_per_launch": alg_bytes},

@@ -11,7 +11,7 @@ mkdir -p $OUT
 cd $R
 python3 bench.py --steps 20 --warmup 3 > $OUT/${TAG}_bench.json 2> $OUT/bench.err
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu --no-workloads > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err || tail -5 $OUT/rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-workloads --headline-only > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err || tail -5 $OUT/rocprof.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 cd $R
 bash tools/pmc_kpe.sh $TAG > $OUT/pmc.log 2>&1 || tail -5 $OUT/pmc.log
