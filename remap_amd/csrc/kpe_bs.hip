@@ -25,6 +25,9 @@
 namespace rmx {
 
 constexpr uint32_t KPE_BS_RA_MAX = 30;  // rows per strip (a multiple of 6; row index: 5 bits of a list entry)
+#ifndef RMX_BS_S1
+#define RMX_BS_S1 2  // candidates per thread and pass of the finish's first stage
+#endif
 #ifndef RMX_BS_LIST
 #define RMX_BS_LIST 2048
 #endif
@@ -378,8 +381,14 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   kpe_bs_body(p, s_c, s_f, s_col);
   RMX_STAMP();  // 1: streamed
   const uint32_t lane = tid & 63u, wv = tid >> 6;
-  uint32_t cnt = 0;  // this thread's candidates
-  for (uint32_t k = 0; k < RA; ++k) cnt += (uint32_t)__builtin_popcount(s_c[k][tid]);
+  uint32_t cnt = 0;  // this thread's candidates (RA is a multiple of six: six words in flight)
+  for (uint32_t k0 = 0; k0 < RA; k0 += 6) {
+    uint32_t w[6];
+#pragma unroll
+    for (uint32_t j = 0; j < 6; ++j) w[j] = s_c[k0 + j][tid];
+#pragma unroll
+    for (uint32_t j = 0; j < 6; ++j) cnt += (uint32_t)__builtin_popcount(w[j]);
+  }
   uint32_t incl = cnt;
 #pragma unroll
   for (int o = 1; o < 64; o <<= 1) {
@@ -424,31 +433,36 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
     __syncthreads();  // the previous round is done (first round: s_fcnt, s_ns)
     if (my_base < r0 + KPE_BS_LIST && my_base + cnt > r0) {
       uint32_t idx = my_base;
-      for (uint32_t k = 0; k < RA && idx < r0 + KPE_BS_LIST; ++k) {
-        uint32_t w = s_c[k][tid];
-        const uint32_t c = (uint32_t)__builtin_popcount(w);
-        if (idx + c <= r0) {
+      for (uint32_t k0 = 0; k0 < RA && idx < r0 + KPE_BS_LIST; k0 += 6) {
+        uint32_t w6[6];
+#pragma unroll
+        for (uint32_t j = 0; j < 6; ++j) w6[j] = s_c[k0 + j][tid];
+#pragma unroll
+        for (uint32_t j = 0; j < 6; ++j) {
+          uint32_t w = w6[j];
+          const uint32_t c = (uint32_t)__builtin_popcount(w);
+          if (idx + c <= r0) w = 0;  // (all before this round)
+          else
+            while (w) {
+              const uint32_t b = (uint32_t)__builtin_ctz(w);
+              w &= w - 1;
+              const uint32_t at = idx + c - 1u - (uint32_t)__builtin_popcount(w);  // rank of bit b among the word's bits
+              if (at >= r0 && at < r0 + KPE_BS_LIST) s_list[at - r0] = tid | (k0 + j) << 8 | b << 13;
+            }
           idx += c;
-          continue;
-        }
-        while (w) {
-          const uint32_t b = (uint32_t)__builtin_ctz(w);
-          w &= w - 1;
-          if (idx >= r0 && idx < r0 + KPE_BS_LIST) s_list[idx - r0] = tid | k << 8 | b << 13;
-          ++idx;
         }
       }
     }
     __syncthreads();
     if (r0 == 0) RMX_STAMP();  // 3: listed
     const uint32_t m = min(KPE_BS_LIST, total - r0);
-    // stage 1: two candidates per thread and pass, both gathers in flight before the first test
-    for (uint32_t k0 = 0; k0 < m; k0 += 512) {
+    // stage 1: RMX_BS_S1 candidates per thread and pass, all gathers in flight before the first test
+    for (uint32_t k0 = 0; k0 < m; k0 += 256 * RMX_BS_S1) {
       if (k0 + (tid & ~63u) >= m) break;  // this wave's lanes are past the round's last candidate
-      uint32_t e[2], x[2], y[2], f[2];
-      CandData d[2];
+      uint32_t e[RMX_BS_S1], x[RMX_BS_S1], y[RMX_BS_S1], f[RMX_BS_S1];
+      CandData d[RMX_BS_S1];
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < RMX_BS_S1; ++c) {
         const uint32_t k = k0 + 256 * c + tid;
         e[c] = k < m ? s_list[k] : 0xffffffffu;
         x[c] = 2, y[c] = 2, f[c] = fwg;
@@ -456,7 +470,7 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
         gather_candidate(p, x[c], y[c], f[c], d[c]);
       }
 #pragma unroll
-      for (int c = 0; c < 2; ++c) {
+      for (int c = 0; c < RMX_BS_S1; ++c) {
         if (k0 + 256 * c + (tid & ~63u) >= m) break;  // uniform
         const bool kp = e[c] != 0xffffffffu && bs_is_keypoint(x[c], d[c]);
         const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
