@@ -172,7 +172,7 @@ def other_workloads(torch, args):
         d[i:i + 1000] = torch.from_numpy(upscale2(small[i:i + 1000])).cuda()
     res["config4_doubled"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes),
                                   workload=f"{n} frames 640x480 = scroller-v1 pixel-doubled (configs[3] 'upscaled capture'; a doubled "
-                                           "patch rarely yields keypoints: no frame matches, in the reference as here)")
+                                           "patch rarely yields keypoints — ~4 per frame — so about one frame in ten opens a new fragment)")
     al = Aligner(640, 480, kmax=4096)
     al.align(d, blit=True)
     torch.cuda.synchronize()

@@ -33,8 +33,9 @@ def _stream_640(kind, n, dens=200):
 def test_config4_640x480_prefix_equals_oracle(gpu, kind):
     """kpe (medians, descriptor tables), kpm (per-region tickets, matched, offsets) and frc (positions,
     fragment ids) of 120 frames at 640x480 — other bands, other table sizes than 320x240 — against the
-    oracle.  The pixel-doubled stream has few keypoints (a doubled 5x5 patch rarely has p3 != p5) and, in
-    the reference as here, no frame matches; the native one follows the generator's ground truth."""
+    oracle.  The pixel-doubled stream has few keypoints (a doubled 5x5 patch rarely has p3 != p5: ~4 per
+    frame), so some frames find no match and open a new fragment — in the oracle as here; the native one
+    follows the generator's ground truth."""
     import torch
 
     n = 120
