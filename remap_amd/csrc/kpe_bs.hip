@@ -25,6 +25,13 @@
 namespace rmx {
 
 constexpr uint32_t KPE_BS_RA_MAX = 30;  // rows per strip (a multiple of 6; row index: 5 bits of a list entry)
+#ifndef RMX_BS_ST_AUX
+#define RMX_BS_ST_AUX 2  // cache policy of the median stores (gfx950: 1 sc0, 2 nt, 16 sc1): nt, they are not read again and
+                         // leave the L2 to the frames' lines the finish gathers from (0.405 -> 0.39 ms)
+#endif
+#ifndef RMX_BS_LD_AUX
+#define RMX_BS_LD_AUX 0
+#endif
 #ifndef RMX_BS_S1
 #define RMX_BS_S1 2  // candidates per thread and pass of the finish's first stage
 #endif
@@ -180,8 +187,8 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
     BsRaw w;
     const int ra = min(max(ya + j, 0), H - 1), rb = min(max(yb + j, 0), H - 1);
     const uint32_t vo = j <= RA ? voff : 0xffffffffu;
-    w.a = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, (uint32_t)(ra * W), 0);
-    w.b = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, (uint32_t)(rb * W), 0);
+    w.a = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, (uint32_t)(ra * W), RMX_BS_LD_AUX);
+    w.b = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, (uint32_t)(rb * W), RMX_BS_LD_AUX);
     return w;
   };
   // A 16-byte store reads its data registers a moment after it issues: an instruction that overwrites them
@@ -193,8 +200,8 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
     const u32x4 va = {a4[0], a4[1], a4[2], a4[3]}, vb = {b4[0], b4[1], b4[2], b4[3]};
     const uint32_t voa = oa < H ? voff_st : 0xffffffffu, vob = ob < H ? voff_st : 0xffffffffu;
     __builtin_amdgcn_sched_barrier(0);
-    __builtin_amdgcn_raw_buffer_store_b128(va, rout, voa, (uint32_t)(oa * W), 0);
-    __builtin_amdgcn_raw_buffer_store_b128(vb, rout, vob, (uint32_t)(ob * W), 0);
+    __builtin_amdgcn_raw_buffer_store_b128(va, rout, voa, (uint32_t)(oa * W), RMX_BS_ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(vb, rout, vob, (uint32_t)(ob * W), RMX_BS_ST_AUX);
     asm volatile("s_nop 1");
     __builtin_amdgcn_sched_barrier(0);
   };
@@ -380,6 +387,9 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   for (uint32_t k = 0; k < RA; ++k) s_c[k][tid] = 0;
   kpe_bs_body(p, s_c, s_f, s_col);
   RMX_STAMP();  // 1: streamed
+#if defined(RMX_BS_FINPRIO)  /* experiment: the finishing phase issues ahead of other workgroups' streaming waves */
+  __builtin_amdgcn_s_setprio(RMX_BS_FINPRIO);
+#endif
   const uint32_t lane = tid & 63u, wv = tid >> 6;
   uint32_t cnt = 0;  // this thread's candidates (RA is a multiple of six: six words in flight)
   for (uint32_t k0 = 0; k0 < RA; k0 += 6) {
@@ -467,7 +477,13 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
         e[c] = k < m ? s_list[k] : 0xffffffffu;
         x[c] = 2, y[c] = 2, f[c] = fwg;
         if (e[c] != 0xffffffffu) decode(e[c], x[c], y[c], f[c]);
+#if defined(RMX_BS_NOGATHER)  /* ablation: the same loads, all from one window (served by the vector L1) */
+        gather_candidate(p, 2, 2, fwg, d[c]);
+#elif defined(RMX_BS_L2GATHER)  /* ablation: the candidates' own windows, but of the batch's first four frames (L2-resident) */
+        gather_candidate(p, x[c], y[c], f[c] & 3u, d[c]);
+#else
         gather_candidate(p, x[c], y[c], f[c], d[c]);
+#endif
       }
 #pragma unroll
       for (int c = 0; c < RMX_BS_S1; ++c) {
