@@ -133,6 +133,18 @@ int rmx_kpm_seq(rmx_ctx* ctx, const rmx_desc* desc, const uint32_t* kcount, uint
                 const rmx_desc* halo_desc, const uint32_t* halo_kcount, int32_t* dxdy,
                 uint8_t* matched);
 
+/* Adaptive launch set for rmx_kpm_seq (off by default).  The matcher is a chain of kernel instances sized for
+ * frames of growing density; on: the context's first step launches all of them and notes which found work, later
+ * steps launch those only.  A step that needed an instance that was not launched reports flag 128 in
+ * rmx_kpm_status like any other ticket left to rmx_kpm_resolve, which then redoes the step with every instance
+ * (and adds what it used to the set): callers that handle flag 128 need nothing else.  Results are the same
+ * either way; what changes is that idle 50-140 KB-LDS instances no longer wait for a CU while another stream's
+ * extraction kernel fills the chip.  Calling it again resets what was learned. */
+int rmx_kpm_adaptive(rmx_ctx* ctx, int on);
+/* The instances the next rmx_kpm_seq launches: bit 0 kpm_build_small64, 1 / 2 kpm_build_medium<256> / <512>,
+ * 3 the general build, 4-6 kpm_match tiers 0-2 (kpm_build_small, kpm_match_pair and kpm_declare always run). */
+uint32_t rmx_kpm_launch_set(rmx_ctx* ctx);
+
 /* Synchronises; returns RMX_ERR_CAPACITY if a matcher workspace limit (groups per frame,
  * shared codes or distinct offsets per region pair) was exceeded since the last call —
  * the affected results are then invalid.  *flags (may be NULL) receives the limit bits:

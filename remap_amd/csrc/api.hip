@@ -45,6 +45,14 @@ struct rmx_ctx {
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   bool kpe_bs = false;         // 3x3 pass on bit planes (kpe_bs.hip): widths that are multiples of 16 (RMX_KPE_BS=0: kpe_mf)
   uint32_t bs_ra = 12;         // rows per strip of kpe_bs (two strips per workgroup)
+  // rmx_kpm_seq's launch set (KPM_TIER_* bits, kpm.hip).  Adaptive: the first step of the context launches every
+  // instance of the build / match chains and learns which found work; later steps launch those only — an instance
+  // with 50-140 KB of LDS that has nothing to do still waits for a CU to drain when another stream's extraction
+  // kernel fills the chip, and the whole chain behind it.  A step that needed one that was not launched reports
+  // flag 128 and is redone by rmx_kpm_resolve with all of them; the set grows by what that pass used.
+  bool kpm_adaptive = false;
+  bool kpm_learned = false;
+  uint32_t kpm_tiers = 127u;
   // launch shape of kpe_fused for this context's frames (plan_fused); ok = false: kpe_main + kpe_finish
   struct FusedPlan {
     bool ok = false, v16 = false;

@@ -761,6 +761,8 @@ __global__ __launch_bounds__(256) void kpm_build_small(KpmBuildParams p, uint32_
     work[work_stride] = 0;
     work[2 * work_stride] = 0;
     if (p.big) p.big[0] = 0;
+    p.status[13] = 0;
+    p.status[14] = 0;
   }
   kpm_build_small_frame<32, true>(p, needs_large, blockIdx.x);
 }
@@ -952,8 +954,16 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
 // tier words of all its frames side by side first and only walks them if one asks for this
 // instance: on a stream where kpm_build_small builds
 // everything these launches cost their launch overhead, not n mostly empty workgroups.
+// status[13]: the instances of the chain that found work in this step (bit per instance, KPM_TIER_*); status[14]:
+// instances a frame or a work item was waiting for but which were not launched (kpm_declare) — rmx_kpm_seq with
+// the adaptive launch set, api_kpm_fgm.inc.
+enum : uint32_t { KPM_TIER_SMALL64 = 1, KPM_TIER_MEDIUM256 = 2, KPM_TIER_MEDIUM512 = 4, KPM_TIER_GENERAL = 8,
+                  KPM_TIER_MATCH0 = 16, KPM_TIER_MATCH1 = 32, KPM_TIER_MATCH2 = 64, KPM_TIER_ALL = 127 };
+__device__ __forceinline__ void kpm_mark_used(uint32_t* status, uint32_t bit) {
+  if (!(__atomic_load_n(&status[13], __ATOMIC_RELAXED) & bit)) atomicOr(&status[13], bit);
+}
 template <typename F>
-__device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want, uint32_t nslots, F&& frame) {
+__device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want, uint32_t nslots, uint32_t* status, uint32_t bit, F&& frame) {
   // workgroup b owns frames b, b + G, b + 2G, ... (neighbouring frames cost alike: striding
   // spreads them over the workgroups)
   const uint32_t G = gridDim.x, b = blockIdx.x;
@@ -966,6 +976,7 @@ __device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want
     for (uint32_t kk = base; kk < end; ++kk) {
       const uint32_t fslot = b + kk * G;
       if (tier && tier[fslot] != want) continue;  // uniform
+      if (threadIdx.x == 0) kpm_mark_used(status, bit);
       frame(fslot);
       __syncthreads();  // LDS is reused by the next frame
     }
@@ -973,9 +984,9 @@ __device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want
 }
 template <uint32_t KC, uint32_t NT, uint32_t BUCKETS>
 __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t* needs_large, uint32_t nslots) {
-  kpm_for_tier(needs_large, 3u, nslots, [&](uint32_t fslot) { kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot); });
+  kpm_for_tier(needs_large, 3u, nslots, p.status, KPM_TIER_GENERAL, [&](uint32_t fslot) { kpm_build_frame<KC, NT, BUCKETS>(p, needs_large, fslot); });
   if (p.big)  // tier 5: frames beyond the pool's layout (kpm_build_small_frame)
-    kpm_for_tier(needs_large, 5u, nslots, [&](uint32_t fslot) {
+    kpm_for_tier(needs_large, 5u, nslots, p.status, KPM_TIER_GENERAL, [&](uint32_t fslot) {
       if (threadIdx.x == 0) {
         const bool is_halo = fslot == p.n;
         const uint32_t q0 = is_halo ? 0u : fslot;
@@ -991,11 +1002,11 @@ __global__ __launch_bounds__(NT) void kpm_build(KpmBuildParams p, const uint32_t
 }
 // tier 4: a wave per region, up to 64 entries per region
 __global__ __launch_bounds__(512) void kpm_build_small64(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
-  kpm_for_tier(tier, 4u, nslots, [&](uint32_t fslot) { kpm_build_small_frame<64, false>(p, tier, fslot); });
+  kpm_for_tier(tier, 4u, nslots, p.status, KPM_TIER_SMALL64, [&](uint32_t fslot) { kpm_build_small_frame<64, false>(p, tier, fslot); });
 }
 template <uint32_t RC, uint32_t TIN>
 __global__ __launch_bounds__(512) void kpm_build_medium(KpmBuildParams p, uint32_t* tier, uint32_t nslots) {
-  kpm_for_tier(tier, TIN, nslots, [&](uint32_t fslot) { kpm_build_medium_frame<RC, TIN>(p, tier, fslot); });
+  kpm_for_tier(tier, TIN, nslots, p.status, TIN == 1 ? KPM_TIER_MEDIUM256 : KPM_TIER_MEDIUM512, [&](uint32_t fslot) { kpm_build_medium_frame<RC, TIN>(p, tier, fslot); });
 }
 
 // ---- matching --------------------------------------------------------------------------------------
@@ -1130,6 +1141,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
   // TIER 0: one (pair, region) per workgroup.  Above: a fixed grid walks the work list the
   // tier below appended to (no launch of n*8 mostly empty workgroups).
   const uint32_t it_end = p.work_in[0];
+  if (blockIdx.x == 0 && lane == 0 && it_end) kpm_mark_used(p.status, KPM_TIER_MATCH0 << TIER);
   for (uint32_t it = blockIdx.x; it < it_end; it += gridDim.x) {
   const uint32_t item = p.work_in[1 + it];
   const uint32_t q = item / p.nreg, r = item % p.nreg;
@@ -1686,12 +1698,36 @@ struct KpmDeclareParams {
   int32_t* dxdy;
   uint8_t* matched;
   uint32_t n, kmax, nreg, has_halo, region_votes;
+  // instances of the chain that were NOT launched in this step (KPM_TIER_* bits; 0 = all were): a frame whose
+  // tier word still names one of them, or a work list left for one, turns the step into one rmx_kpm_resolve
+  // has to redo (status[1] |= 128, status[14] = which)
+  uint32_t skipped;
+  const uint32_t* tier;  // n + has_halo tier words (kpm_build_small)
+  const uint32_t* work;  // the three work lists' counters, work_stride words apart
+  uint32_t work_stride;
+  uint32_t* status;
 };
 
 // kpm.hpp:395-415 tail: get_active, count (Borda), top_offsets(…, 2), declare.
 __global__ void kpm_declare(KpmDeclareParams p) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= p.n) return;
+  if (p.skipped) {
+    auto waits_for = [](uint32_t tw) -> uint32_t {
+      return tw == 4u ? KPM_TIER_SMALL64 : tw == 1u ? KPM_TIER_MEDIUM256 : tw == 2u ? KPM_TIER_MEDIUM512 : (tw == 3u || tw == 5u) ? KPM_TIER_GENERAL : 0u;
+    };
+    uint32_t miss = waits_for(p.tier[q]);
+    if (q == 0) {
+      if (p.has_halo) miss |= waits_for(p.tier[p.n]);
+      for (uint32_t t = 0; t < 3; ++t)
+        if (p.work[t * p.work_stride]) miss |= KPM_TIER_MATCH0 << t;
+    }
+    miss &= p.skipped;
+    if (miss) {
+      atomicOr(&p.status[14], miss);
+      atomicOr(&p.status[1], 128u);
+    }
+  }
   int32_t dx = 0, dy = 0;
   uint8_t ok = 0;
   if (q > 0 || p.has_halo) {

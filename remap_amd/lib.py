@@ -38,6 +38,7 @@ SYMBOLS = [
     "rmx_debug_umap_order",
     "rmx_debug_kpe_scratch",
     "rmx_fgm_blit_fresh",
+    "rmx_kpm_adaptive", "rmx_kpm_launch_set",
 ]
 
 
@@ -103,6 +104,9 @@ def load():
     lib.rmx_kpe_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
     lib.rmx_kpm_status.argtypes = [vp, C.POINTER(u32)]
+    lib.rmx_kpm_adaptive.argtypes = [vp, C.c_int]
+    lib.rmx_kpm_launch_set.argtypes = [vp]
+    lib.rmx_kpm_launch_set.restype = u32
     lib.rmx_kpm_resolve.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32)]
     lib.rmx_debug_umap_order.argtypes = [vp, vp, u32, vp]
     lib.rmx_debug_kpe_scratch.argtypes = [vp, vp, C.c_size_t]
@@ -271,6 +275,14 @@ class Context:
         order = self.torch.empty(hashes.shape[0], dtype=self.torch.int32, device=self.device)
         self._chk(self.lib.rmx_debug_umap_order(self.h, hashes.data_ptr(), hashes.shape[0], order.data_ptr()), "rmx_debug_umap_order")
         return order
+
+    def kpm_adaptive(self, on=True):
+        """rmx_kpm_seq launches only the matcher instances this context's stream has needed so far (a step that
+        needs another reports flag 128 and kpm_resolve redoes it): for callers that handle flag 128."""
+        self._chk(self.lib.rmx_kpm_adaptive(self.h, 1 if on else 0), "rmx_kpm_adaptive")
+
+    def kpm_launch_set(self):
+        return int(self.lib.rmx_kpm_launch_set(self.h))
 
     def kpm_status(self):
         fl = C.c_uint32()

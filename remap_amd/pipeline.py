@@ -168,6 +168,7 @@ class Aligner:
 
         self.torch = torch
         self.ctx = L.Context(width, height, grid=(4, 2), overlap=16, kmax=kmax, device=device)
+        self.ctx.kpm_adaptive(True)  # (_check_step resolves flag 128, which is all the adaptive launch set asks for)
         self.W, self.H, self.kmax = width, height, kmax
         self.dist = dist if (dist is not None and dist.is_initialized()) else None
         self.group = group
@@ -454,7 +455,8 @@ class AlignerPipe:
     of block t + 1.  The extraction kernels themselves take turns (an event between the lanes):
     two of them side by side only share the chip, and each would take twice as long.
 
-    Every block is a step of its own, as with `Aligner.align(defer=True)`; `finish()` waits for
+    Every block is a step of its own, as with `Aligner.align(defer=True)`: its results are final once it
+    has been settled — by `settle(out)`, by its lane's next block, or by `finish()`, which waits for
     all lanes and returns the fragment count of the last block (raises if any block overflowed).
     With several ranks the lanes share one process group: its collectives run in issue order,
     which is the same on every rank."""
@@ -493,6 +495,19 @@ class AlignerPipe:
         with t.cuda.stream(s):
             return self.lanes[i].align(frames, n_total=n_total, defer=True,
                                        kpe_gate=(before_kpe, after_kpe) if len(self.lanes) > 1 else None)
+
+    def settle(self, out):
+        """Wait for the block that returned `out` and complete it (status words; a block that has tickets left
+        for rmx_kpm_resolve, or that needed a matcher instance outside its lane's launch set, is redone and
+        scanned again): its offsets and positions are final after this — or once its lane has taken its next
+        block, or after finish().  Returns its fragment count."""
+        for lane, s in zip(self.lanes, self.streams):
+            if lane._deferred is not None and lane._deferred[0] is out:
+                with self.torch.cuda.stream(s):
+                    r = lane._settle()
+                self.torch.cuda.current_stream(self.device).wait_stream(s)
+                return r
+        return out["nfrag"]
 
     def finish(self):
         t = self.torch

@@ -384,3 +384,50 @@ def test_unordered_map_order_replay_at_scale(gpu, n, kind):
     got = ctx.debug_umap_order(torch.from_numpy(h.view(np.int64)).cuda()).cpu().numpy().astype(np.uint32)
     ctx.close()
     assert np.array_equal(got, want)
+
+
+def test_adaptive_launch_set_learns_and_recovers(gpu):
+    """rmx_kpm_adaptive (what Aligner switches on): the first step launches every instance of the matcher's
+    chains and keeps those that found work; a later block that needs another one (a dense block after sparse
+    ones: wave-per-region builds, the per-(pair, region) match tiers) is flagged, redone with all of them by
+    the resolve pass of the step's check, and the set grows — offsets, positions and fragment ids equal those
+    of a context that always launches everything, block for block."""
+    import torch
+
+    from remap_amd.pipeline import Aligner
+
+    sparse, _ = scroller_v1(300, dens=200)
+    dense, _ = scroller_v1(300, dens=40, cam_seed=5)
+    d_sparse, d_dense = torch.from_numpy(sparse).cuda(), torch.from_numpy(dense).cuda()
+    ref = Aligner(320, 240, kmax=4096)
+    ref.ctx.kpm_adaptive(False)
+    assert ref.ctx.kpm_launch_set() == 127
+    want = {}
+    for name, blk in (("sparse", d_sparse), ("dense", d_dense)):
+        o = ref.align(blk)
+        want[name] = ({k: o[k].clone() for k in ("dxdy", "matched", "pos", "frag")}, o["nfrag"])
+    ref.close()
+
+    def same(out, name):
+        w, nf = want[name]
+        return out["nfrag"] == nf and all(torch.equal(out[k], v) for k, v in w.items())
+
+    al = Aligner(320, 240, kmax=4096)
+    assert al.ctx.kpm_launch_set() == 127  # nothing learned yet: the first step launches all
+    assert same(al.align(d_sparse), "sparse")
+    learned = al.ctx.kpm_launch_set()
+    assert learned != 127 and not learned & 64  # (no sparse frame reaches the 136-KB match tier)
+    assert same(al.align(d_sparse), "sparse") and al.ctx.kpm_launch_set() == learned
+    assert same(al.align(d_dense), "dense")  # needs instances outside the set: redone, same results
+    grown = al.ctx.kpm_launch_set()
+    assert grown & learned == learned and grown != learned and grown & 2  # (kpm_build_medium<256> builds dense frames)
+    assert same(al.align(d_dense), "dense") and al.ctx.kpm_launch_set() == grown
+    # deferred steps: the flagged step is settled (and redone) before its buffers are used again
+    al2 = Aligner(320, 240, kmax=4096)
+    al2.align(d_sparse, defer=True)
+    al2.align(d_sparse, defer=True)
+    out = al2.align(d_dense, defer=True)
+    al2.finish()
+    assert same(out, "dense")
+    al2.close()
+    al.close()
