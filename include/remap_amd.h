@@ -75,6 +75,15 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
                    rmx_ctx** out);
 int rmx_ctx_destroy(rmx_ctx* ctx);
 int rmx_sync(rmx_ctx* ctx);
+/* Contexts of ONE device that hold blocks of a stream in flight, each on its own HIP stream: their extraction
+ * kernels take turns.  rmx_kpe_batch then waits (on the device) for the extraction kernel the group launched
+ * last before launching its own, and the context's table kernels and everything behind them run beside the
+ * next context's extraction kernel.  Two extraction kernels side by side only share the chip; the matcher's
+ * small kernels leave most of it idle.  n = 1 (or a context named in a later call) leaves the group.
+ * rmx_kpe_wait_turn makes the context's stream wait for that last extraction kernel without launching one
+ * (for a canvas blit that should not run beside it). */
+int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n);
+int rmx_kpe_wait_turn(rmx_ctx* ctx);
 const char* rmx_last_error(const rmx_ctx* ctx);
 /* Number of bytes of device workspace the context currently holds (diagnostics). */
 size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx);
@@ -346,6 +355,9 @@ int rmx_debug_umap_order(rmx_ctx* ctx, const uint64_t* hashes, uint32_t n, uint3
  * kpe_main / kpe_finish; in builds with -DRMX_BS_STAMP the phase time stamps of kpe_bs's workgroups, eight
  * 64-bit words each, tools/bs_stamps.py) to host memory.  Synchronises.  No counterpart in the reference. */
 int rmx_debug_kpe_scratch(rmx_ctx* ctx, void* host_dst, size_t bytes);
+/* Diagnostics: the context's 64 device status words (flags, scan carry, launch-set words, and in builds with
+ * -DRMX_STATS / -DRMX_KPM_STAMP the matcher's counters and phase times).  Synchronises. */
+int rmx_debug_status(rmx_ctx* ctx, uint32_t* host_words64);
 
 #ifdef __cplusplus
 }

@@ -2,6 +2,7 @@
 // One translation unit: the kernel files are included so a single hipcc invocation builds
 // libremap_amd.so for gfx950.
 #include <hip/hip_runtime.h>
+#include <memory>
 
 #include <algorithm>
 #include <cstdio>
@@ -50,6 +51,12 @@ struct rmx_ctx {
   // with 50-140 KB of LDS that has nothing to do still waits for a CU to drain when another stream's extraction
   // kernel fills the chip, and the whole chain behind it.  A step that needed one that was not launched reports
   // flag 128 and is redone by rmx_kpm_resolve with all of them; the set grows by what that pass used.
+  // contexts of one pipeline (blocks of a stream in flight on streams of their own) whose extraction kernels
+  // take turns: a context waits for the extraction kernel the group launched last and leaves its own as the
+  // one to wait for — recorded right behind the extraction kernel, before the table kernels (rmx_kpe_take_turns)
+  struct KpeTurns { hipEvent_t last = nullptr; };
+  std::shared_ptr<KpeTurns> turns;
+  hipEvent_t turn_ev = nullptr;
   bool kpm_adaptive = false;
   bool kpm_learned = false;
   uint32_t kpm_tiers = 127u;
@@ -314,6 +321,10 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
   if (ctx->fdf_ws) (void)hipFree(ctx->fdf_ws);
   if (ctx->pack_buf) (void)hipFree(ctx->pack_buf);
+  if (ctx->turn_ev) {
+    if (ctx->turns && ctx->turns->last == ctx->turn_ev) ctx->turns->last = nullptr;
+    (void)hipEventDestroy(ctx->turn_ev);
+  }
   for (auto e : ctx->ev_main) (void)hipEventDestroy(e);
   for (auto e : ctx->ev_fin) (void)hipEventDestroy(e);
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
@@ -321,6 +332,30 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   kpm_workspace_free(ctx->kpm);
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) free_track(*t);
   delete ctx;
+  return RMX_OK;
+}
+
+int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n) {
+  if (!ctxs || n == 0) return RMX_ERR_ARG;
+  for (uint32_t i = 0; i < n; ++i)
+    if (!ctxs[i] || ctxs[i]->device != ctxs[0]->device) return RMX_ERR_ARG;
+  auto turns = std::make_shared<rmx_ctx::KpeTurns>();
+  for (uint32_t i = 0; i < n; ++i) {
+    rmx_ctx* ctx = ctxs[i];
+    RMX_HIP(hipSetDevice(ctx->device));
+    if (!ctx->turn_ev) RMX_HIP(hipEventCreateWithFlags(&ctx->turn_ev, hipEventDisableTiming));
+    if (ctx->turns && ctx->turns->last == ctx->turn_ev) ctx->turns->last = nullptr;
+    ctx->turns = n > 1 ? turns : nullptr;
+  }
+  return RMX_OK;
+}
+
+int rmx_kpe_wait_turn(rmx_ctx* ctx) {
+  if (!ctx) return RMX_ERR_ARG;
+  if (ctx->turns && ctx->turns->last && ctx->turns->last != ctx->turn_ev) {
+    RMX_HIP(hipSetDevice(ctx->device));
+    RMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->turns->last, 0));
+  }
   return RMX_OK;
 }
 
@@ -510,6 +545,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
       ctx->ev_fin.push_back(b);
     }
   }
+  if (int rc = rmx_kpe_wait_turn(ctx)) return rc;
   uint32_t sub_idx = 0;
   if (ctx->fused.ok) {
     const rmx_ctx::FusedPlan& pl = ctx->fused;
@@ -623,6 +659,10 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   }
   if (overlap)
     for (uint32_t i = 0; i < sub_idx; ++i) RMX_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_fin[i], 0));
+  if (ctx->turns) {
+    RMX_HIP(hipEventRecord(ctx->turn_ev, ctx->stream));
+    ctx->turns->last = ctx->turn_ev;
+  }
   TableParams tp{};
   tp.raw = ctx->raw;
   tp.kcount = ctx->kraw;

@@ -798,6 +798,19 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   __shared__ uint32_t s_big;
 
   if (tier[fslot] != TIN) return;  // uniform: built already, or not yet examined
+#if defined(RMX_KPM_STAMP)  /* diagnostic build (tools/kpm_phases.py): time per phase, summed over the region waves, in status[40..] */
+  uint64_t stamp_t = __builtin_amdgcn_s_memtime();
+  uint32_t stamp_i = 40;
+#define KPM_STAMP()                                                                            \
+  {                                                                                            \
+    const uint64_t now = __builtin_amdgcn_s_memtime();                                         \
+    if ((threadIdx.x & 63u) == 0) atomicAdd(&p.status[stamp_i], (uint32_t)(now - stamp_t));    \
+    ++stamp_i;                                                                                 \
+    stamp_t = now;                                                                             \
+  }
+#else
+#define KPM_STAMP()
+#endif
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * (p.tstride ? p.tstride : p.kmax);
   uint32_t k = is_halo ? p.halo_kcount[0] : p.kcount[fslot];
@@ -828,6 +841,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     return;
   }
   if (threadIdx.x == 0) tier[fslot] = 0u;
+  KPM_STAMP();  // 40: entries
   uint32_t slots = 16, G = 0, w2 = 0, w1 = 0;
   if (mine) {
     // 2. group by code
@@ -861,6 +875,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
       w1 += (uint32_t)__shfl_xor((int)w1, o);
     }
     wbar();
+    KPM_STAMP();  // 41: grouped
     // 3. order entries by (first occurrence of their code, scan order)
     uint32_t n2 = 1;
     while (n2 < e) n2 <<= 1;
@@ -876,6 +891,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
       for (uint32_t sl = 0; sl < RC / 64; ++sl) keys[r][sl * 64 + lane] = kreg[sl];
     }
     wbar();
+    KPM_STAMP();  // 42: sorted
     // 4. number the groups (first-occurrence order)
     for (uint32_t base = 0; base < e; base += 64) {
       const uint32_t j = base + lane;
@@ -898,8 +914,10 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     s_e[r] = 0;
     s_g[r] = 0;
   }
+  if (mine) KPM_STAMP();  // 43: numbered
   __syncthreads();
   if (!mine) return;
+  KPM_STAMP();  // 44: waited for the other regions
   uint32_t p_off = 0, g_off = 0, ht_off = 0;
   for (uint32_t q = 0; q < r; ++q) {
     p_off += s_e[q];
@@ -943,11 +961,14 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     h[H_W1] = w1;
   }
   wbar();
+  KPM_STAMP();  // 45: exported
   // iteration order of this region's code map.  Scratch: keys[r] is free again; the region's
   // hash table (exported above) now holds seq_a (RC u16) and the bucket minima behind it, and
   // slot_of[r] (last read when the sort keys were formed) holds seq_b
   umap_order_par<64, RC>(hg[r], G, keys[r], reinterpret_cast<uint16_t*>(htl[r]), slot_of[r], htl[r] + RC / 2, wbar,
                          pool + kpm_off_giter(p.kmax) + g_off, lane);
+  KPM_STAMP();  // 46: map order
+#undef KPM_STAMP
 }
 
 // The instances behind kpm_build_small are launched on a FIXED grid; a workgroup looks at the

@@ -36,10 +36,18 @@ SYMBOLS = [
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
     "rmx_debug_umap_order",
-    "rmx_debug_kpe_scratch",
+    "rmx_debug_kpe_scratch", "rmx_debug_status",
     "rmx_fgm_blit_fresh",
-    "rmx_kpm_adaptive", "rmx_kpm_launch_set",
+    "rmx_kpm_adaptive", "rmx_kpm_launch_set", "rmx_kpe_take_turns", "rmx_kpe_wait_turn",
 ]
+
+
+def kpe_take_turns(contexts):
+    """The extraction kernels of these contexts (one device, a stream each) take turns: rmx_kpe_take_turns."""
+    arr = (C.c_void_p * len(contexts))(*[getattr(c.h, "value", c.h) for c in contexts])
+    rc = contexts[0].lib.rmx_kpe_take_turns(arr, len(contexts))
+    if rc != RMX_OK:
+        raise RemapError(rc, "rmx_kpe_take_turns")
 
 
 class RemapError(RuntimeError):
@@ -100,6 +108,8 @@ def load():
     lib.rmx_ctx_create.argtypes = [C.c_int, u32, u32, u32, u32, u32, u32, vp, C.POINTER(vp)]
     lib.rmx_ctx_destroy.argtypes = [vp]
     lib.rmx_sync.argtypes = [vp]
+    lib.rmx_kpe_take_turns.argtypes = [C.POINTER(vp), u32]
+    lib.rmx_kpe_wait_turn.argtypes = [vp]
     lib.rmx_kpe_batch.argtypes = [vp, vp, u32, vp, vp, vp]
     lib.rmx_kpe_status.argtypes = [vp, C.POINTER(u32)]
     lib.rmx_kpm_seq.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp]
@@ -110,6 +120,7 @@ def load():
     lib.rmx_kpm_resolve.argtypes = [vp, vp, vp, u32, vp, vp, vp, vp, C.POINTER(u32)]
     lib.rmx_debug_umap_order.argtypes = [vp, vp, u32, vp]
     lib.rmx_debug_kpe_scratch.argtypes = [vp, vp, C.c_size_t]
+    lib.rmx_debug_status.argtypes = [vp, vp]
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]
     lib.rmx_frc_scan.argtypes = [vp, vp, vp, u32, C.c_int, C.POINTER(i32), C.POINTER(u32), vp, vp]
     lib.rmx_frc_scan_block.argtypes = [vp, vp, vp, u32, C.c_int, vp, vp, vp]
@@ -280,6 +291,10 @@ class Context:
         """rmx_kpm_seq launches only the matcher instances this context's stream has needed so far (a step that
         needs another reports flag 128 and kpm_resolve redoes it): for callers that handle flag 128."""
         self._chk(self.lib.rmx_kpm_adaptive(self.h, 1 if on else 0), "rmx_kpm_adaptive")
+
+    def kpe_wait_turn(self):
+        """This context's stream waits for the extraction kernel its group launched last (kpe_take_turns)."""
+        self._chk(self.lib.rmx_kpe_wait_turn(self.h), "rmx_kpe_wait_turn")
 
     def kpm_launch_set(self):
         return int(self.lib.rmx_kpm_launch_set(self.h))

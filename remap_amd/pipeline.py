@@ -187,7 +187,7 @@ class Aligner:
             self._bufs[name] = b
         return b
 
-    def align(self, frames, n_total=None, blit=False, check=True, compress=False, defer=False, kpe_gate=None):
+    def align(self, frames, n_total=None, blit=False, check=True, compress=False, defer=False):
         """One pass of the hot path over this rank's block `frames` (n, H, W) uint8 on device.
 
         Returns a dict with device tensors for the LOCAL block (frames lo..hi of the stream):
@@ -216,11 +216,7 @@ class Aligner:
         median = self._buf("median", frames.shape, t.uint8)
         desc = self._buf("desc", (n, self.kmax, L.DESC_BYTES), t.uint8)
         kcount = self._buf("kcount", (n,), t.int32)
-        if kpe_gate is not None:  # (AlignerPipe: the extraction kernels of consecutive steps take turns)
-            kpe_gate[0]()
-        ctx.kpe(frames, median, desc, kcount)
-        if kpe_gate is not None:
-            kpe_gate[1]()
+        ctx.kpe(frames, median, desc, kcount)  # (AlignerPipe: the extraction kernels of its lanes take turns, rmx_kpe_take_turns)
         halo = None
         if self.world > 1:
             tabs, cnts = gather_boundary_tables(desc[n - 1], kcount[n - 1:n], self.dist, self.group)
@@ -471,8 +467,9 @@ class AlignerPipe:
         for s in self.streams:
             with torch.cuda.stream(s):  # (a Context adopts the stream that is current when it is made)
                 self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=group))
+        if lanes > 1:
+            L.kpe_take_turns([a.ctx for a in self.lanes])
         self._turn = 0
-        self._kpe_done = None
         self._pending = [None] * lanes
 
     def align(self, frames, n_total=None):
@@ -483,18 +480,8 @@ class AlignerPipe:
         s.wait_stream(t.cuda.current_stream(self.device))  # the frames were produced there
         frames.record_stream(s)  # ... and are read on this lane's stream: not to be recycled under it
 
-        def before_kpe():
-            if self._kpe_done is not None:
-                s.wait_event(self._kpe_done)
-
-        def after_kpe():
-            ev = t.cuda.Event()
-            ev.record(s)
-            self._kpe_done = ev
-
         with t.cuda.stream(s):
-            return self.lanes[i].align(frames, n_total=n_total, defer=True,
-                                       kpe_gate=(before_kpe, after_kpe) if len(self.lanes) > 1 else None)
+            return self.lanes[i].align(frames, n_total=n_total, defer=True)
 
     def settle(self, out):
         """Wait for the block that returned `out` and complete it (status words; a block that has tickets left
@@ -574,8 +561,7 @@ class AlignerPipe:
                 # extraction that is under way, this lane's next one follows it in stream order
                 # (the wait goes right before the blit's kernels: the host-side stage — positions to
                 # the host, extents — runs while that extraction kernel does)
-                ev, s = self._kpe_done, self.streams[i]
-                lane.blit_gate = (lambda: s.wait_event(ev)) if (ev is not None and len(self.lanes) > 1) else None
+                lane.blit_gate = lane.ctx.kpe_wait_turn if len(self.lanes) > 1 else None
                 out["canvases"] = lane.blit(frames, out["pos_all"], out["frag_all"], out["lo"], out["hi"])
                 lane.blit_gate = None
         return out
