@@ -595,6 +595,10 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   __shared__ uint32_t okeys[8][KS_RC], bmin[8][KS_BK];
   __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big, s_maxe;
+  // the frame's rows (this instance: k <= 256), staged once and coalesced: region masks, codes and coordinates
+  // come from LDS afterwards instead of five dependent trips to global memory per frame
+  __shared__ uint4 s_row[256];   // code bytes 0..12, region mask, x
+  __shared__ uint32_t s_xy[256];  // x | y << 16
 
   const bool is_halo = fslot == p.n;
   const rmx_desc* desc = is_halo ? p.halo_desc : p.desc + (size_t)fslot * (p.tstride ? p.tstride : p.kmax);
@@ -622,6 +626,16 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
     s_big = k > 256 ? 1u : 0u;
     s_maxe = 0;
   }
+  if (k <= 256 && threadIdx.x < k) {
+    uint4 v;
+    __builtin_memcpy(&v, desc + threadIdx.x, 16);
+    s_row[threadIdx.x] = v;
+    s_xy[threadIdx.x] = load_xy(desc + threadIdx.x);
+  }
+  auto code_of = [&](uint32_t i, uint32_t (&cc)[4]) {
+    const uint4 v = s_row[i];
+    cc[0] = v.x, cc[1] = v.y, cc[2] = v.z, cc[3] = v.w & 0xffu;
+  };
   __syncthreads();
   const bool mine = r < p.nreg && k <= 256;
   // 1. region entries in scan order
@@ -629,7 +643,7 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   if (k <= 256) {  // (uniform; every lane takes part in the ballots)
     for (uint32_t base = 0; base < k; base += LPR) {
       uint32_t i = base + lane;
-      bool in = mine && i < k && ((desc[i].region_mask >> r) & 1u);
+      bool in = mine && i < k && ((s_row[i].w >> (8 + r)) & 1u);
       uint64_t bal = gballot(in);
       uint32_t pos = e + gcount_below(bal);
       if (in && pos < KS_RC) ent[r][pos] = (uint16_t)i;
@@ -659,13 +673,13 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     if (mine && lane < e) {
-      load_code(desc + ent[r][lane], c);
+      code_of(ent[r][lane], c);
       uint32_t s = fnv_code_lo(c) & mask;
       for (;;) {
         uint32_t v = atomicCAS(&htl[r][s], EMPTY, lane);
         if (v == EMPTY) break;
         uint32_t c2[4];
-        load_code(desc + ent[r][v], c2);
+        code_of(ent[r][v], c2);
         if (same_code(c, c2)) {
           atomicMin(&htl[r][s], lane);
           break;
@@ -712,13 +726,12 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
   uint32_t* ght = pool + kpm_off_ht(p.kmax);
   if (mine && lane < e) {
-    const rmx_desc* d = desc + ent[r][key & 0xffffu];
-    pts[p_off + lane] = load_xy(d);
+    pts[p_off + lane] = s_xy[ent[r][key & 0xffffu]];
     if (start) {
       gstart[g_off + r + gid] = p_off + lane;
       gfirst[g_off + gid] = ent[r][first];
       uint32_t cf[4];
-      load_code(desc + ent[r][first], cf);
+      code_of(ent[r][first], cf);
       hg[r][gid] = fnv_code(cf);
       store_gcode(pool, p.kmax, g_off + gid, cf);
       gid_of[r][first] = (uint16_t)gid;  // rank of a group's first entry -> group id
@@ -784,8 +797,8 @@ __device__ __forceinline__ uint32_t wave_exscan(uint32_t v, uint32_t lane, uint3
   return incl - v;
 }
 
-// RC = entries per region the instance holds (256: 53 KB of LDS, three workgroups per CU;
-// 512: 104 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
+// RC = entries per region the instance holds (256: 53 + 25 KB of LDS, two workgroups per CU;
+// 512: 104 + 40 KB, one); a frame enters at tier TIN and leaves at 0 (built) or TIN + 1.
 template <uint32_t RC, uint32_t TIN>
 __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, uint32_t* tier, uint32_t fslot) {
   // (the map-order scratch lives in arrays that are dead by then: see the umap_order_par call;
@@ -796,17 +809,23 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   static_assert(RC / 2 + (RC == 256 ? 257 : 541) <= 2 * RC, "seq_a + bmin must fit the region's hash table");
   __shared__ uint32_t s_e[8], s_g[8];
   __shared__ uint32_t s_big;
+  // The frame's table rows, staged once by the whole workgroup (coalesced): every later phase reads codes,
+  // region masks and coordinates from LDS; a frame with more rows than fit goes on to the next instance.  (From global memory each of the eight region waves
+  // scanned all k masks, and grouping / numbering / export were chains of dependent 16-byte loads: 73 us per
+  // frame for ~1 100 rows, four fifths of it waiting for those loads — tools/kpm_phases.py.)
+  constexpr uint32_t KS = RC == 256 ? 1280 : 2048;
+  __shared__ uint4 s_row[KS];   // code bytes 0..12, region mask, x
+  __shared__ uint32_t s_xy[KS];  // x | y << 16
 
   if (tier[fslot] != TIN) return;  // uniform: built already, or not yet examined
 #if defined(RMX_KPM_STAMP)  /* diagnostic build (tools/kpm_phases.py): time per phase, summed over the region waves, in status[40..] */
   uint64_t stamp_t = __builtin_amdgcn_s_memtime();
-  uint32_t stamp_i = 40;
-#define KPM_STAMP()                                                                            \
-  {                                                                                            \
-    const uint64_t now = __builtin_amdgcn_s_memtime();                                         \
-    if ((threadIdx.x & 63u) == 0) atomicAdd(&p.status[stamp_i], (uint32_t)(now - stamp_t));    \
-    ++stamp_i;                                                                                 \
-    stamp_t = now;                                                                             \
+  uint32_t stamp_d[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, stamp_i = 0;  // (added to the status words at the end: nothing of it inside the phases)
+#define KPM_STAMP()                                            \
+  {                                                            \
+    const uint64_t now = __builtin_amdgcn_s_memtime();         \
+    stamp_d[stamp_i++] = (uint32_t)(now - stamp_t);            \
+    stamp_t = now;                                             \
   }
 #else
 #define KPM_STAMP()
@@ -819,7 +838,22 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   const uint32_t r = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t EMPTY = 0xffffffffu;
   const WaveBarrier wbar{};
+  if (k > KS) {  // uniform: more rows than the staging area holds (no region-sized instance reads rows from global memory:
+                 // a global load in a loop that also stores makes every store wait for the one before, s_waitcnt vmcnt(0))
+    if (threadIdx.x == 0) tier[fslot] = TIN + 1u;
+    return;
+  }
   if (threadIdx.x == 0) s_big = 0u;
+  for (uint32_t i = threadIdx.x; i < k; i += blockDim.x) {
+    uint4 v;
+    __builtin_memcpy(&v, desc + i, 16);
+    s_row[i] = v;
+    s_xy[i] = load_xy(desc + i);
+  }
+  auto code_of = [&](uint32_t i, uint32_t (&c)[4]) {
+    const uint4 v = s_row[i];
+    c[0] = v.x, c[1] = v.y, c[2] = v.z, c[3] = v.w & 0xffu;
+  };
   __syncthreads();
   const bool mine = r < p.nreg;
   // 1. region entries in scan order
@@ -827,7 +861,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   if (mine) {
     for (uint32_t base = 0; base < k; base += 64) {
       uint32_t i = base + lane;
-      bool in = i < k && ((desc[i].region_mask >> r) & 1u);
+      bool in = i < k && ((s_row[i].w >> (8 + r)) & 1u);
       uint64_t bal = __builtin_amdgcn_ballot_w64(in);
       uint32_t pos = e + mbcnt(bal);
       if (in && pos < RC) ent[r][pos] = (uint16_t)i;
@@ -851,7 +885,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     wbar();
     for (uint32_t i = lane; i < e; i += 64) {
       uint32_t c[4];
-      load_code(desc + ent[r][i], c);
+      code_of(ent[r][i], c);
       const uint32_t wgt = c[3] & 0xfu;
       w2 += wgt == 2u;
       w1 += wgt == 1u;
@@ -860,7 +894,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
         uint32_t v = atomicCAS(&htl[r][s], EMPTY, i);
         if (v == EMPTY) break;
         uint32_t c2[4];
-        load_code(desc + ent[r][v], c2);
+        code_of(ent[r][v], c2);
         if (same_code(c, c2)) {
           atomicMin(&htl[r][s], i);
           break;
@@ -901,7 +935,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
         const uint32_t gid = G + mbcnt(sb), first = keys[r][j] >> 16;
         gid_of[r][first] = (uint16_t)gid;
         uint32_t cf[4];
-        load_code(desc + ent[r][first], cf);
+        code_of(ent[r][first], cf);
         hg[r][gid] = fnv_code(cf);
       }
       G += (uint32_t)__builtin_popcountll(sb);
@@ -914,7 +948,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     s_e[r] = 0;
     s_g[r] = 0;
   }
-  if (mine) KPM_STAMP();  // 43: numbered
+  KPM_STAMP();  // 43: numbered
   __syncthreads();
   if (!mine) return;
   KPM_STAMP();  // 44: waited for the other regions
@@ -933,21 +967,23 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
   uint32_t* ght = pool + kpm_off_ht(p.kmax);
   for (uint32_t j = lane; j < e; j += 64) {
     const uint32_t first = keys[r][j] >> 16, i = keys[r][j] & 0xffffu;
-    const rmx_desc* d = desc + ent[r][i];
-    pts[p_off + j] = load_xy(d);
+    const uint32_t row = ent[r][i];
+    pts[p_off + j] = s_xy[row];
     if (j == 0 || first != (keys[r][j - 1] >> 16)) {
       const uint32_t gid = gid_of[r][first];
       gstart[g_off + r + gid] = p_off + j;
       gfirst[g_off + gid] = ent[r][first];
       uint32_t cf[4];
-      load_code(d, cf);  // j is the group's first entry
+      code_of(row, cf);  // j is the group's first entry
       store_gcode(pool, p.kmax, g_off + gid, cf);
     }
   }
+  KPM_STAMP();  // 45: points and groups exported
   for (uint32_t sidx = lane; sidx < slots; sidx += 64) {
     const uint32_t v = htl[r][sidx];
     ght[ht_off + sidx] = v == EMPTY ? 0u : (uint32_t)gid_of[r][v] + 1u;
   }
+  KPM_STAMP();  // 46: code index exported
   if (lane == 0) {
     gstart[g_off + r + G] = p_off + e;
     uint32_t* h = pool + r * 8;
@@ -961,13 +997,17 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
     h[H_W1] = w1;
   }
   wbar();
-  KPM_STAMP();  // 45: exported
+  KPM_STAMP();  // 47: header
   // iteration order of this region's code map.  Scratch: keys[r] is free again; the region's
   // hash table (exported above) now holds seq_a (RC u16) and the bucket minima behind it, and
   // slot_of[r] (last read when the sort keys were formed) holds seq_b
   umap_order_par<64, RC>(hg[r], G, keys[r], reinterpret_cast<uint16_t*>(htl[r]), slot_of[r], htl[r] + RC / 2, wbar,
                          pool + kpm_off_giter(p.kmax) + g_off, lane);
-  KPM_STAMP();  // 46: map order
+  KPM_STAMP();  // 48: map order
+#if defined(RMX_KPM_STAMP)
+  if ((threadIdx.x & 63u) == 0)
+    for (uint32_t i = 0; i < 9; ++i) atomicAdd(&p.status[40 + i], stamp_d[i]);
+#endif
 #undef KPM_STAMP
 }
 

@@ -1,5 +1,5 @@
 """Phase times of kpm_build_medium (a library built with -DRMX_KPM_STAMP, RMX_SO): s_memtime ticks per phase
-summed over the region waves, read from the context's status words 40..46.
+summed over the region waves, read from the context's status words 40..48.
 usage: RMX_SO=ab/bs_kpmstamp.so python tools/kpm_phases.py [n] [dens]"""
 import ctypes as C
 import os
@@ -22,7 +22,7 @@ torch.cuda.synchronize()
 buf = (C.c_uint32 * 64)()
 rc = ctx.lib.rmx_debug_status(ctx.h, buf)
 assert rc == 0
-t = np.array(buf[40:47], dtype=np.float64)
-names = ["entries", "grouped (hash)", "sorted", "groups numbered", "waited for other regions", "exported", "map order"]
+t = np.array(buf[40:49], dtype=np.float64)
+names = ["entries", "grouped (hash)", "sorted", "groups numbered", "waited for other regions", "points and groups exported", "code index exported", "header", "map order"]
 for nm, v in zip(names, t):
     print(f"{nm:28s} {v / t.sum() * 100:5.1f} %   {v / (8 * n) / 100:.2f} us per region wave")
