@@ -216,6 +216,9 @@ constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
 // rows of a wave's tile and frames in its pipe (measured: 8 x 2..8 and 4 x 4..8 within 3 %, 16 rows slower);
 // the byte-per-lane kernel for narrow frames holds two frames of 4 rows in registers
 constexpr int BL_ROWS = 8, BL_DEPTH = 4, BL_ROWS_NARROW = 4;
+#ifndef RMX_BLIT_SYNC
+#define RMX_BLIT_SYNC 16  // list positions between two barriers of a workgroup's waves (a divisor of 64; 0: none): 2.17 -> 1.43 GB fetched per 10 000 frames, same time (4: also 1.43 GB, +10 % time)
+#endif
 constexpr uint32_t BL_DIRECT_MAX = 1024;  // batches up to this many frames skip the binning passes
 
 // A frame overlaps at most W/256 + 2 groups; three tiny passes bin the batch's frames by
@@ -491,8 +494,26 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
     uint32_t w_info = 0;
     int w_fy0 = 0;
     uint4 rec_next = blit_record(p, base + lane, lend);
+#if RMX_BLIT_SYNC
+    // The four waves of a workgroup hold x-neighbouring tiles and walk the same list: a 128-byte line of a
+    // frame's row is needed by two (three) of them.  Left to themselves they drift apart by tens of frames and
+    // each fetches its own copy from beyond the L2 (2.9 fetches per line); here a batch of 64 records is
+    // served in windows of RMX_BLIT_SYNC list positions with a workgroup barrier between the windows — the same
+    // number of barriers for every wave, whatever its tile matches — so neighbours ask for a line within a few
+    // frames of each other.  (Waves without a tile have left: the barrier counts the remaining ones.)
+    uint64_t todo_all = 0;
+    uint32_t sub = 64 / RMX_BLIT_SYNC;
+#endif
     auto refill = [&]() -> bool {  // false: the list is exhausted
       while (todo == 0) {
+#if RMX_BLIT_SYNC
+        if (sub < 64 / RMX_BLIT_SYNC) {
+          todo = todo_all & (((RMX_BLIT_SYNC == 64 ? 0ull : (1ull << (RMX_BLIT_SYNC & 63))) - 1ull) << (sub * RMX_BLIT_SYNC));
+          ++sub;
+          __builtin_amdgcn_s_barrier();
+          continue;
+        }
+#endif
         if (base >= lend) return false;
         const uint4 rec = rec_next;
         const bool live = rec.w != 0;
@@ -511,7 +532,12 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
         w_base = (uint64_t)rec.x * fbytes + (uint64_t)((FULL ? (uint32_t)fy0 * (uint32_t)W : 0u) + (uint32_t)sxc);  // (W H < 2^32)
         w_info = (uint32_t)(sx - sxc + 64) | rows << 16;
         w_fy0 = fy0;
+#if RMX_BLIT_SYNC
+        todo_all = __builtin_amdgcn_ballot_w64(live && full == FULL && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
+        sub = 0;
+#else
         todo = __builtin_amdgcn_ballot_w64(live && full == FULL && ay < Y0 + R && ay + H > Y0 && ax < X0 + BL_TW && ax + W > X0);
+#endif
       }
       return true;
     };
