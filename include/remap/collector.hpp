@@ -15,8 +15,10 @@
 #include <exception>
 #include <list>
 #include <optional>
+#include <future>
 #include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "core.hpp"
@@ -238,6 +240,19 @@ public:
     exact_callbacks_ = on;
     return *this;
   }
+  // The next block of the feed is produced by a helper thread while the current one is on the device and in its
+  // callbacks.  Off by default: the feeder then runs concurrently with the callbacks (never with itself), which
+  // the reference's single loop never does — for feeders that share no unsynchronised state with them
+  // (main.cpp's file_feed and counting callback qualify).
+  // frames per block (default block_frames; smaller blocks: less host and device memory, more launches)
+  collector& block_size(std::uint32_t frames) noexcept {
+    block_size_ = std::max<std::uint32_t>(1, frames);
+    return *this;
+  }
+  collector& prefetch_feed(bool on) noexcept {
+    prefetch_feed_ = on;
+    return *this;
+  }
 
   template <typename Feeder, typename Comp, typename Callback>
   void collect(Feeder&& feed, Comp&& comp, Callback&& cb)
@@ -249,16 +264,25 @@ public:
     std::int32_t carry_pos[2] = {0, 0};
     std::uint32_t carry_frag = 0;
     remap::detail::phase_clock clk;
-    while (feed.has_more()) {
-      clk.mark(nullptr);
-      // ---- drain one block of the feed into the host arena (reused block after block: its pages are
-      // touched once), stage it into HBM ----
-      all::memory_pool& pool = feed_pool_;
+    // ---- the feed is drained in blocks into one of two host arenas (reused block after block: their pages are
+    // touched once).  With prefetch_feed(true) the NEXT block is produced by a helper thread while this one is
+    // on the device and in its callbacks; otherwise after them, on this thread (the reference's order of calls
+    // per block) ----
+    std::vector<frame_type> block, next_block;
+    unsigned cur = 0;
+    auto fill = [&](std::vector<frame_type>& b, all::memory_pool& pool) {
+      b.clear();
       pool.reset();
-      std::vector<frame_type> block;
-      while (feed.has_more() && block.size() < block_frames) block.push_back(feed.produce(pixel_alloc_t{pool}));
+      while (feed.has_more() && b.size() < block_size_) b.push_back(feed.produce(pixel_alloc_t{pool}));
+    };
+    std::future<void> pending;  // (declared after the blocks: joined before they go)
+    clk.mark(nullptr);
+    fill(block, feed_pool_[0]);
+    clk.mark("feed.produce");
+    while (!block.empty()) {
+      clk.mark(nullptr);
+      if (prefetch_feed_) pending = std::async(std::launch::async, [&, nxt = cur ^ 1u] { fill(next_block, feed_pool_[nxt]); });
       const std::uint32_t n = std::uint32_t(block.size());
-      clk.mark("feed.produce");
       std::uint32_t maxk = 0;
       const std::int32_t carry_pos0[2] = {carry_pos[0], carry_pos[1]};
       const std::uint32_t carry_frag0 = carry_frag;
@@ -270,7 +294,7 @@ public:
         std::uint8_t* stage = stage_.template get<std::uint8_t>();  // (thread_local: this thread's buffer)
         const unsigned gatherers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
         auto gather = [&, stage](unsigned w) {
-          for (std::uint32_t i = w; i < n; i += gatherers) std::memcpy(stage + i * area, block[i].image_.data(), area);
+          for (std::uint32_t i = w; i < n; i += gatherers) std::memcpy(stage + i * area, std::as_const(block[i].image_).data(), area);  // (const: a view stays a view)
         };
         std::vector<std::thread> helpers;
         for (unsigned w = 1; w < gatherers; ++w) helpers.emplace_back(gather, w);
@@ -335,7 +359,6 @@ public:
       remap::check(rmx_download(ctx_, h_pos_.data(), pos_.get(), 8 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_frag_.data(), frag_.get(), 4 * n), ctx_, "rmx_download");
       remap::check(rmx_download(ctx_, h_k_.data(), kcount_.get(), 4 * n), ctx_, "rmx_download");
-      remap::check(rmx_download(ctx_, h_med_.get(), median_.get(), n * area), ctx_, "rmx_download");
       remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax_ * sizeof(rmx_desc),
                                    tstride * sizeof(rmx_desc), n),
                    ctx_, "rmx_download_2d");
@@ -357,11 +380,16 @@ public:
       all::memory_pool arena;
       std::vector<std::optional<image_type>> medians(n);
       std::vector<std::optional<grid_type>> grids(n);
+      // (the block's medians cross PCIe in one copy, when the first of them is read: a host-side compressor does
+      // that with frame 0, main.cpp's callback with nic::compression never does)
+      mrl::cell_loader med_loader{[&] {
+        remap::check(rmx_download(ctx_, h_med_.get(), median_.get(), std::size_t(n) * area), ctx_, "rmx_download");
+      }};
       {
         const auto* med_src = reinterpret_cast<cpl::nat_cc const*>(h_med_.template get<std::uint8_t>());
         const auto* tab_src = h_tab_.data();
         for (std::uint32_t t = 0; t < n; ++t) {
-          medians[t].emplace(image_type::view(dim_, med_src + std::size_t(t) * area, pixel_alloc_t{arena}));
+          medians[t].emplace(image_type::view(dim_, med_src + std::size_t(t) * area, pixel_alloc_t{arena}, &med_loader));
           if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
           grids[t].emplace(remap::detail::table_to_grid_deferred<grid_type>(tab_src + std::size_t(t) * tstride, h_k_[t],
                                                                             allocator_t<char>{arena}));
@@ -406,6 +434,11 @@ public:
       remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
       clk.mark("blit + replay (callbacks)");
       first = false;
+      if (prefetch_feed_) pending.get();
+      else fill(next_block, feed_pool_[cur ^ 1u]);
+      clk.mark(prefetch_feed_ ? "feed.produce (what the helper thread had left)" : "feed.produce");
+      std::swap(block, next_block);
+      cur ^= 1u;
     }
   }
 
@@ -459,7 +492,9 @@ private:
   rmx_ctx* ctx_;
   std::uint32_t kmax_{kmax};
   bool exact_callbacks_{false};
-  all::memory_pool feed_pool_;  // the frames of the block in flight (feed.produce allocates from it)
+  bool prefetch_feed_{false};
+  std::uint32_t block_size_{block_frames};
+  all::memory_pool feed_pool_[2];  // the frames of the block in flight and of the next one (feed.produce allocates from them)
   remap::device_buffer frames_, median_, desc_, kcount_, dxdy_, matched_, pos_, frag_, halo_;
   std::vector<std::int32_t> h_pos_;
   std::vector<std::uint32_t> h_frag_, h_k_;

@@ -10,6 +10,7 @@
 #pragma once
 
 #include <algorithm>
+#include <functional>
 #include <array>
 #include <compare>
 #include <concepts>
@@ -148,6 +149,19 @@ using region_t = cdt::region<size_type>;
 // image (frc.hpp:119) straight out of the page-locked buffer the block came back in, instead of copying
 // 76 800 bytes per frame for a callback that, in main.cpp, does not look at it.  Any write access (and any
 // copy) turns the view into an owning matrix first.
+// What fills the memory a group of views borrows, run once, by whichever view is read first (frc::collector:
+// the medians of a block come back from the device in ONE copy, and only if a callback looks at one).
+struct cell_loader {
+  std::function<void()> fill;
+  bool done{false};
+  void ensure() {
+    if (!done) {
+      fill();
+      done = true;
+    }
+  }
+};
+
 template <typename T, typename Alloc = std::allocator<T>>
 class matrix {
 public:
@@ -161,34 +175,41 @@ public:
   matrix(dimensions_t d) : matrix(d, allocator_type{}) {}
   matrix(dimensions_t d, T const& v) : matrix(d, v, allocator_type{}) {}
   // borrowed cells: valid while `cells` is (the collector's callbacks: for the duration of the call)
-  static matrix view(dimensions_t d, T const* cells, allocator_type const& a = allocator_type{}) {
+  // `loader` (optional, same lifetime as `cells`): run before the cells are first read
+  static matrix view(dimensions_t d, T const* cells, allocator_type const& a = allocator_type{}, cell_loader* loader = nullptr) {
     matrix m{a};
     m.dim_ = d;
     m.borrowed_ = cells;
+    m.loader_ = loader;
     return m;
   }
   matrix(matrix const& o) : dim_{o.dim_}, cells_{o.cells_.get_allocator()} { cells_.assign(o.data(), o.end()); }
-  matrix(matrix&& o) noexcept : dim_{o.dim_}, cells_{std::move(o.cells_)}, borrowed_{o.borrowed_} { o.dim_ = {}, o.borrowed_ = nullptr; }
+  matrix(matrix&& o) noexcept : dim_{o.dim_}, cells_{std::move(o.cells_)}, borrowed_{o.borrowed_}, loader_{o.loader_} {
+    o.dim_ = {}, o.borrowed_ = nullptr, o.loader_ = nullptr;
+  }
   matrix& operator=(matrix const& o) {
     if (this != &o) {
       dim_ = o.dim_;
       cells_.assign(o.data(), o.end());
-      borrowed_ = nullptr;
+      borrowed_ = nullptr, loader_ = nullptr;
     }
     return *this;
   }
   matrix& operator=(matrix&& o) noexcept {
-    dim_ = o.dim_, cells_ = std::move(o.cells_), borrowed_ = o.borrowed_;
-    o.dim_ = {}, o.borrowed_ = nullptr;
+    dim_ = o.dim_, cells_ = std::move(o.cells_), borrowed_ = o.borrowed_, loader_ = o.loader_;
+    o.dim_ = {}, o.borrowed_ = nullptr, o.loader_ = nullptr;
     return *this;
   }
 
   T& operator[](size_type i) { return own()[i]; }
-  T const& operator[](size_type i) const noexcept { return data()[i]; }
+  T const& operator[](size_type i) const { return data()[i]; }
   T* data() { return own(); }
-  T const* data() const noexcept { return borrowed_ ? borrowed_ : cells_.data(); }
+  T const* data() const {
+    if (loader_) loader_->ensure();
+    return borrowed_ ? borrowed_ : cells_.data();
+  }
   T* end() { return own() + size(); }
-  T const* end() const noexcept { return data() + size(); }
+  T const* end() const { return data() + size(); }
   size_type width() const noexcept { return dim_.width_; }
   size_type height() const noexcept { return dim_.height_; }
   size_type size() const noexcept { return borrowed_ ? dim_.area() : cells_.size(); }
@@ -223,14 +244,16 @@ public:
 private:
   T* own() {
     if (borrowed_) {
+      if (loader_) loader_->ensure();
       cells_.assign(borrowed_, borrowed_ + dim_.area());
-      borrowed_ = nullptr;
+      borrowed_ = nullptr, loader_ = nullptr;
     }
     return cells_.data();
   }
   dimensions_t dim_{};
   std::vector<T, Alloc> cells_;
   T const* borrowed_{nullptr};
+  cell_loader* loader_{nullptr};
 };
 
 }  // namespace mrl

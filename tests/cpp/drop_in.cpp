@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <cstdlib>
 #include <string>
 
 #include "frc.hpp"
@@ -26,6 +27,25 @@ public:
     image_type img{dim_, alloc};
     std::memcpy(img.data(), blob_->data() + next_ * dim_.area(), dim_.area());
     return ifd::frame<image_type>{next_++, std::move(img)};
+  }
+
+private:
+  mrl::dimensions_t dim_;
+  std::vector<std::uint8_t> const* blob_;
+  std::size_t next_{0};
+};
+
+// a feed whose frames are already in host memory: the images are views on the blob (no copy in the feeder; the
+// collector's gather into its page-locked staging buffer is the one copy before PCIe)
+class mem_view_feed {
+public:
+  mem_view_feed(mrl::dimensions_t d, std::vector<std::uint8_t> const& blob) : dim_{d}, blob_{&blob} {}
+  bool has_more() const noexcept { return next_ * dim_.area() < blob_->size(); }
+  template <typename Alloc>
+  auto produce(Alloc const& alloc) {
+    using image_type = sid::nat::aimg_t<Alloc>;
+    auto const* px = reinterpret_cast<typename image_type::value_type const*>(blob_->data() + next_ * dim_.area());
+    return ifd::frame<image_type>{next_++, image_type::view(dim_, px, alloc)};
   }
 
 private:
@@ -159,20 +179,22 @@ static int run_fdf(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob)
 }
 
 // throughput of frc::collector::collect through the drop-in layer (host feed, callbacks and all)
-static int run_time(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob, bool codec) {
+template <typename Feed>
+static int run_time(mrl::dimensions_t dim, std::vector<std::uint8_t> const& blob, bool codec, char const* feed_name) {
   for (int rep = 0; rep < 2; ++rep) {  // the second pass has the context, workspace and pools warm
     frc::collector collector{dim};
+    collector.prefetch_feed(std::getenv("REMAP_NO_PREFETCH") == nullptr);  // (the feed and the counting callback share nothing)
     std::size_t calls = 0;
     auto cb = [&](fgm::fragment const&, frc::frame_type const&, frc::image_type const&, frc::grid_type const&) { ++calls; };
     const auto t0 = std::chrono::steady_clock::now();
     if (codec)
-      collector.collect(mem_feed{dim, blob}, nic::compression{}, cb);
+      collector.collect(Feed{dim, blob}, nic::compression{}, cb);
     else
-      collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
+      collector.collect(Feed{dim, blob}, noop_compression{}, cb);
     auto frags = collector.complete();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("collect pass %d: %zu frames, %zu fragments, %.3f s, %.0f frames/s (%s)\n", rep, calls + 1, frags.size(), dt,
-                double(calls + 1) / dt, codec ? "nic::compression" : "no-op codec");
+    std::printf("collect pass %d: %zu frames, %zu fragments, %.3f s, %.0f frames/s (%s, %s)\n", rep, calls + 1, frags.size(), dt,
+                double(calls + 1) / dt, codec ? "nic::compression" : "no-op codec", feed_name);
   }
   return 0;
 }
@@ -228,8 +250,10 @@ int main(int argc, char** argv) {
   if (argc > 4 && std::string(argv[4]) == "splice") return run_splice(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "nic") return run_nic(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "fdf") return run_fdf(dim, blob);
-  if (argc > 4 && std::string(argv[4]) == "time") return run_time(dim, blob, false);
-  if (argc > 4 && std::string(argv[4]) == "timenic") return run_time(dim, blob, true);
+  if (argc > 4 && std::string(argv[4]) == "time") return run_time<mem_feed>(dim, blob, false, "copying feed");
+  if (argc > 4 && std::string(argv[4]) == "timenic") return run_time<mem_feed>(dim, blob, true, "copying feed");
+  if (argc > 4 && std::string(argv[4]) == "timeview") return run_time<mem_view_feed>(dim, blob, false, "view feed");
+  if (argc > 4 && std::string(argv[4]) == "timeviewnic") return run_time<mem_view_feed>(dim, blob, true, "view feed");
   if (argc > 4 && std::string(argv[4]) == "twice") return run_twice(dim, blob);
   if (argc > 4 && std::string(argv[4]) == "exact") return run_exact(dim, blob);
 
@@ -245,6 +269,8 @@ int main(int argc, char** argv) {
     for (auto& r : grid.regions()) entries += r.total_count();
     for (auto const* p = median.data(); p < median.end(); ++p) med_sum += p->value;
   };
+  if (char const* b = std::getenv("REMAP_TEST_BLOCK")) collector.block_size(std::uint32_t(std::atoi(b)));  // (several blocks from a short stream)
+  if (std::getenv("REMAP_TEST_PREFETCH")) collector.prefetch_feed(true);
   collector.collect(mem_feed{dim, blob}, noop_compression{}, cb);
   auto fragments = collector.complete();
 

@@ -35,6 +35,18 @@ def test_collector_drop_in_matches_oracle(gpu, tmp_path):
     check_collect(exe, frames, tmp_path)
 
 
+def test_collector_blocks_with_prefetched_feed(gpu, tmp_path):
+    """The same stream in blocks of 7 frames (halo tables, scan carry and fragment ids across 15 block boundaries),
+    once with the feed drained on the calling thread and once by the helper thread (prefetch_feed): callbacks in
+    order, medians (downloaded when the callback reads them), grids, canvases and positions as the oracle's."""
+    exe = build_driver(str(tmp_path))
+    frames, truth = scroller_v1(100, dens=100)
+    frames = frames.copy()
+    frames[40] = 6  # a fragment break
+    check_collect(exe, frames, tmp_path, env={"REMAP_TEST_BLOCK": "7"})
+    check_collect(exe, frames, tmp_path, env={"REMAP_TEST_BLOCK": "7", "REMAP_TEST_PREFETCH": "1"})
+
+
 def noisy(p, seed):
     rng = np.random.default_rng(seed)
     img = np.full((240, 320), 6, np.uint8)
@@ -91,10 +103,11 @@ def test_collector_takes_frames_of_pure_noise(gpu, tmp_path):
     check_collect(exe, frames, tmp_path)
 
 
-def check_collect(exe, frames, tmp_path):
+def check_collect(exe, frames, tmp_path, env=None):
     blob = tmp_path / "frames.bin"
     frames.tofile(blob)
-    out = subprocess.run([exe, str(blob), "320", "240"], check=True, capture_output=True, text=True).stdout
+    out = subprocess.run([exe, str(blob), "320", "240"], check=True, capture_output=True, text=True,
+                         env=dict(os.environ, **(env or {}))).stdout
     lines = out.strip().splitlines()
     head = dict(zip(lines[0].split()[::2], lines[0].split()[1::2]))
     o = O.orc_frc(frames)

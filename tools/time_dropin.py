@@ -14,7 +14,7 @@ subprocess.check_call(["g++", "-std=c++20", "-O2", "-I" + os.path.join(ROOT, "in
 fr, _ = scroller_v1(n, dens=200)
 blob = os.path.join(tmp, "f.bin")
 fr.tofile(blob)
-for mode in ("time", "timenic"):
+for mode in ("time", "timenic", "timeview", "timeviewnic"):
     r = subprocess.run([exe, blob, "320", "240", mode], check=True, capture_output=True, text=True, env=dict(os.environ, REMAP_PROFILE="1"))
     print(r.stdout.strip())
-    print(r.stderr.strip())
+    print(r.stderr.strip() if os.environ.get("REMAP_PHASES") else "", end="")
