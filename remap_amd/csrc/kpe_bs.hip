@@ -133,7 +133,73 @@ __device__ __forceinline__ uint32_t bs_first_frame(const KpeParams& p, uint32_t 
   const int64_t L0 = (int64_t)g * 62 - 1;
   return (uint32_t)((L0 < 0 ? 0 : (uint64_t)L0) / p.Wd);
 }
-__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t* s_f, uint32_t* s_col) {
+#ifndef RMX_BS_ROLL
+#define RMX_BS_ROLL 0  // 1: the candidates of three row steps are tested inside the row loop (see bs_roll)
+#endif
+constexpr uint32_t KPE_BS_WLIST = 256;  // candidates a wave hands out per round of bs_roll
+
+// stage 1 (is the candidate a keypoint?) for the candidates of the last three row steps of ONE wave, inside the row
+// loop: their 5x5 windows are gathered two to four steps after the stream read those rows, while the lines are
+// still in the L2 (a workgroup that finishes its strips after the walk finds them pushed out by its XCD's other
+// 127 workgroups: 0.04 ms of the kernel).  The wave hands its candidates out densely among its
+// own lanes through a list in LDS; the keypoints' bits are OR-ed into the candidate words the workgroup's finish
+// reads, which then holds keypoints only.
+struct BsRoll {
+  uint32_t (*s_c)[256];
+  const uint32_t* s_f;
+  const uint32_t* s_col;
+  uint32_t* wl;        // this wave's list (KPE_BS_WLIST entries)
+  uint32_t wave_base;  // first thread of the wave
+  uint32_t lane, ya, RA, fallback_f;
+};
+__device__ __forceinline__ bool bs_is_keypoint(uint32_t x, const CandData& d);
+__device__ __forceinline__ void bs_roll(const KpeParams& p, const BsRoll& R, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t k0) {
+  const uint32_t lane = R.lane;
+  const uint32_t c = (uint32_t)(__builtin_popcount(w0) + __builtin_popcount(w1) + __builtin_popcount(w2));
+  uint32_t incl = c;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = (uint32_t)__shfl_up((int)incl, o);
+    if (lane >= (uint32_t)o) incl += t;
+  }
+  const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+  for (uint32_t r0 = 0; r0 < T; r0 += KPE_BS_WLIST) {  // uniform
+    uint32_t idx = incl - c;
+    const uint32_t ws[3] = {w0, w1, w2};
+#pragma unroll
+    for (uint32_t j = 0; j < 3; ++j) {
+      uint32_t w = ws[j];
+      while (w) {
+        const uint32_t b = (uint32_t)__builtin_ctz(w);
+        w &= w - 1;
+        if (idx >= r0 && idx < r0 + KPE_BS_WLIST) R.wl[idx - r0] = lane | j << 6 | b << 8;
+        ++idx;
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t m = min(KPE_BS_WLIST, T - r0);
+    for (uint32_t q0 = 0; q0 < m; q0 += 64) {  // uniform
+      const bool act = q0 + lane < m;
+      const uint32_t e = act ? R.wl[q0 + lane] : 0u;
+      const uint32_t owner = R.wave_base + (e & 63u), j = (e >> 6) & 3u, b = e >> 8;
+      const uint32_t x = act ? R.s_col[owner] * 16 + (b & 15u) : 2u;
+      const uint32_t y = act ? R.ya + (b >> 4) * R.RA + k0 + j : 2u;
+      const uint32_t f = act ? R.s_f[owner] : R.fallback_f;
+      CandData d;
+#if defined(RMX_BS_ROLL_NOGATHER)  /* ablation: the roll's loads from one L1-resident window */
+      gather_candidate(p, 2, 2, R.fallback_f, d);
+#else
+      gather_candidate(p, x, y, f, d);
+#endif
+      if (act && bs_is_keypoint(x, d)) atomicOr(&R.s_c[k0 + j][owner], 1u << b);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
+__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t* s_f, uint32_t* s_col, uint32_t* s_wl) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   s_f[threadIdx.x] = 0;  // (written before the walk: nothing but the thread index lives across it)
@@ -227,14 +293,26 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 #else
 #define RMX_BS_SELECT(A, B, Cn)                                                                            \
   bs::select4of9(A, B, Cn, nr);                                                                            \
-  s_c[jj][threadIdx.x] = bs::differs(nr, B.c, valid);                                                      \
+  RMX_BS_CAND(jj, bs::differs(nr, B.c, valid));                                                            \
   bs::native_planes_of_inverted_rank(nr, nat);                                                             \
   nat[0] &= valid, nat[1] &= valid, nat[2] &= valid, nat[3] &= valid;                                      \
   bs::bytes_from_planes(nat, oa4, ob4);
 #endif
+#if RMX_BS_ROLL
+  uint32_t cdw[3] = {0, 0, 0};
+  BsRoll roll{s_c, s_f, s_col, s_wl + wv * KPE_BS_WLIST, wv * 64u, lane, (uint32_t)ya, (uint32_t)RA, f0};
+#define RMX_BS_CAND(jj, word) cdw[rr % 3] = (word)
+#define RMX_BS_ROLLNOW(R) \
+  if ((R) % 3 == 2) bs_roll(p, roll, cdw[0], cdw[1], cdw[2], (uint32_t)(j + (R) - 2));
+#else
+#define RMX_BS_CAND(jj, word) s_c[jj][threadIdx.x] = (word)
+#define RMX_BS_ROLLNOW(R)
+#endif
 #define RMX_BS_STEP(A, B, Cn, PF, R)                                                                       \
   {                                                                                                        \
     const int jj = j + R;                                                                                  \
+    constexpr int rr = R;                                                                                  \
+    (void)rr;                                                                                              \
     bs_make_row(PF, Cn);                                                                                   \
     PF = load_rows(jj + 1 + RMX_BS_DEPTH);                                                                 \
     const int oa = ya + jj, ob = yb + jj;                                                                  \
@@ -243,6 +321,7 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
     if (!(ob >= 2 && ob + 5 <= H)) valid &= 0x0000ffffu;                                                   \
     uint32_t nr[4], nat[4], oa4[4], ob4[4];                                                                \
     RMX_BS_SELECT(A, B, Cn)                                                                                \
+    RMX_BS_ROLLNOW(R) /* before this step's stores: a wait for the gathers then covers no store younger than a step */ \
     store_rows(oa, ob, oa4, ob4);                                                                          \
   }
   for (int j = 0; j < RA; j += 6) {
@@ -264,6 +343,8 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
   }
 #undef RMX_BS_STEP
 #undef RMX_BS_SELECT
+#undef RMX_BS_CAND
+#undef RMX_BS_ROLLNOW
 }
 
 // ---- finishing the candidates -----------------------------------------------------------------------------
@@ -374,6 +455,11 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   __shared__ uint32_t s_surv[KPE_BS_LIST];  // its keypoints: the same | place among its frame's keypoints of this round << 18
   __shared__ uint32_t s_fcnt[256], s_fbase[256];  // per frame of the workgroup: keypoints of this round, their first table row
   __shared__ uint32_t s_ns;
+#if RMX_BS_ROLL
+  __shared__ uint32_t s_wl[4 * KPE_BS_WLIST];
+#else
+  uint32_t* const s_wl = nullptr;
+#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t RA = p.rows_per_strip;
 #if defined(RMX_BS_STAMP)  /* diagnostic build (tools/bs_stamps.py): phase times of every workgroup, in p.cand */
@@ -385,7 +471,7 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
 #endif
   RMX_STAMP();
   for (uint32_t k = 0; k < RA; ++k) s_c[k][tid] = 0;
-  kpe_bs_body(p, s_c, s_f, s_col);
+  kpe_bs_body(p, s_c, s_f, s_col, s_wl);
   RMX_STAMP();  // 1: streamed
 #if defined(RMX_BS_FINPRIO)  /* experiment: the finishing phase issues ahead of other workgroups' streaming waves */
   __builtin_amdgcn_s_setprio(RMX_BS_FINPRIO);
@@ -477,7 +563,8 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
         e[c] = k < m ? s_list[k] : 0xffffffffu;
         x[c] = 2, y[c] = 2, f[c] = fwg;
         if (e[c] != 0xffffffffu) decode(e[c], x[c], y[c], f[c]);
-#if defined(RMX_BS_NOGATHER)  /* ablation: the same loads, all from one window (served by the vector L1) */
+#if RMX_BS_ROLL  /* the listed candidates ARE the keypoints (bs_roll tested them inside the row loop) */
+#elif defined(RMX_BS_NOGATHER)  /* ablation: the same loads, all from one window (served by the vector L1) */
         gather_candidate(p, 2, 2, fwg, d[c]);
 #elif defined(RMX_BS_L2GATHER)  /* ablation: the candidates' own windows, but of the batch's first four frames (L2-resident) */
         gather_candidate(p, x[c], y[c], f[c] & 3u, d[c]);
@@ -488,7 +575,11 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
 #pragma unroll
       for (int c = 0; c < RMX_BS_S1; ++c) {
         if (k0 + 256 * c + (tid & ~63u) >= m) break;  // uniform
+#if RMX_BS_ROLL
+        const bool kp = e[c] != 0xffffffffu;
+#else
         const bool kp = e[c] != 0xffffffffu && bs_is_keypoint(x[c], d[c]);
+#endif
         const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
         if (km) {
           uint32_t base = 0;
