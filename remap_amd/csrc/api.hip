@@ -46,6 +46,13 @@ struct rmx_ctx {
   uint32_t rps_max = 48;       // longest strip (rows, multiple of 8)
   bool kpe_bs = false;         // 3x3 pass on bit planes (kpe_bs.hip): widths that are multiples of 16 (RMX_KPE_BS=0: kpe_mf)
   uint32_t bs_ra = 12;         // rows per strip of kpe_bs (two strips per workgroup)
+  uint32_t bs_ra_ring = 24;    // ... of kpe_bs_ring (its finish does not care how far behind the stream it runs)
+  // Which finish the bit-plane extraction kernel uses.  kpe_bs_ring (the finish rolled into the row loop, windows
+  // from an LDS ring) is 8 % faster on streams with few keypoints and 20 % slower on dense ones (1 100 per
+  // 320x240 frame): chosen when the last batch whose status words came back had at most one keypoint per 256
+  // pixels (kpe_table samples every 32nd frame's count into status[15]); RMX_BS_RING=0/1 forces it.
+  int bs_ring_forced = -1;
+  bool bs_ring = false;
   // rmx_kpm_seq's launch set (KPM_TIER_* bits, kpm.hip).  Adaptive: the first step of the context launches every
   // instance of the build / match chains and learns which found work; later steps launch those only — an instance
   // with 50-140 KB of LDS that has nothing to do still waits for a CU to drain when another stream's extraction
@@ -296,7 +303,8 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_RPS")) ctx->rps_max = (uint32_t)std::max(8, atoi(e) / 8 * 8);
   ctx->kpe_bs = width % 16 == 0;
   if (const char* e = getenv("RMX_KPE_BS")) ctx->kpe_bs = ctx->kpe_bs && atoi(e) != 0;
-  if (const char* e = getenv("RMX_BS_RA")) ctx->bs_ra = (uint32_t)std::min<int>(std::max(1, atoi(e)), (int)KPE_BS_RA_MAX);
+  if (const char* e = getenv("RMX_BS_RA")) ctx->bs_ra = ctx->bs_ra_ring = (uint32_t)std::min<int>(std::max(1, atoi(e)), (int)KPE_BS_RA_MAX);
+  if (const char* e = getenv("RMX_BS_RING")) ctx->bs_ring_forced = atoi(e) != 0, ctx->bs_ring = atoi(e) != 0;
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
@@ -333,6 +341,13 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) free_track(*t);
   delete ctx;
   return RMX_OK;
+}
+
+// status[15] of the batch whose status words just came back: keypoints of its sampled frames
+static void kpe_note_density(rmx_ctx* ctx, uint32_t sampled_keypoints) {
+  if (ctx->bs_ring_forced >= 0 || ctx->n_last == 0 || ctx->kmax > KPE_KMAX_LDS) return;  // (kpe_table_big does not sample)
+  const uint64_t frames = (ctx->n_last + 31) / 32;
+  ctx->bs_ring = (uint64_t)sampled_keypoints * 256 <= frames * ctx->W * ctx->H;
 }
 
 int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n) {
@@ -594,13 +609,16 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     // chunks of the frames laid back to back + 2 halo lanes
     p.HB = p.Wd <= 64 && 64 % p.Wd <= 8 && !getenv("RMX_BS_HALO") ? 64 / p.Wd : 0;
     if (p.HB) p.groups = (n + p.HB - 1) / p.HB;
-    p.rows_per_strip = std::max(6u, std::min(ctx->bs_ra, (ctx->H + 1) / 2) / 6 * 6);
+    const bool ring = ctx->bs_ring;
+    p.rows_per_strip = std::max(6u, std::min(ring ? ctx->bs_ra_ring : ctx->bs_ra, (ctx->H + 1) / 2) / 6 * 6);
     p.kmax = ctx->kmax;
     p.cand = ctx->cand;  // (diagnostic builds only: phase stamps)
     dim3 grid((p.groups + 3) / 4, (ctx->H + 2 * p.rows_per_strip - 1) / (2 * p.rows_per_strip));
     {
       Timer t(ctx, &ctx->ms_kpe);
-      hipLaunchKernelGGL(kpe_bs, grid, dim3(256), p.rows_per_strip * 256 * sizeof(uint32_t), ctx->stream, p);
+      static const size_t pad_lds = getenv("RMX_BS_PADLDS") ? (size_t)atoi(getenv("RMX_BS_PADLDS")) * 1024 : 0;  // experiment: fewer workgroups per CU
+      if (ring) hipLaunchKernelGGL(kpe_bs_ring, grid, dim3(256), pad_lds, ctx->stream, p);  // (keeps no candidate words)
+      else hipLaunchKernelGGL(kpe_bs, grid, dim3(256), p.rows_per_strip * 256 * sizeof(uint32_t) + pad_lds, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
   }
@@ -714,9 +732,10 @@ int rmx_kpe_status(rmx_ctx* ctx, uint32_t* max_k) {
     st = ctx->cached_status[0];
     ctx->cached_status[0] = 0;
   } else {
-    RMX_HIP(hipMemcpyAsync(ctx->host_words, ctx->status, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    RMX_HIP(hipMemcpyAsync(ctx->host_words, ctx->status, 16 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     RMX_HIP(hipStreamSynchronize(ctx->stream));
     st = ctx->host_words[0];
+    kpe_note_density(ctx, ctx->host_words[15]);
   }
   if (max_k) {  // diagnostic: the per-frame counts are only fetched when asked for
     *max_k = 0;

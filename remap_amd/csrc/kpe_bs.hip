@@ -133,27 +133,87 @@ __device__ __forceinline__ uint32_t bs_first_frame(const KpeParams& p, uint32_t 
   const int64_t L0 = (int64_t)g * 62 - 1;
   return (uint32_t)((L0 < 0 ? 0 : (uint64_t)L0) / p.Wd);
 }
-#ifndef RMX_BS_ROLL
-#define RMX_BS_ROLL 0  // 1: the candidates of three row steps are tested inside the row loop (see bs_roll)
+// ---- the rolling finish (kpe_bs_ring) -------------------------------------------------------------------------
+// The workgroup-wide finish gathers every candidate's 5x5 window from global memory 12 row steps after the
+// stream read those rows: by then they have left the L2 (0.04 ms of the kernel) — and gathering them INSIDE the
+// row loop is no better, the oldest row of a window is seven steps old.  Here a wave keeps the
+// last eight rows it streamed in LDS, two pixels per byte exactly as planes_from_bytes packs them first (16 B
+// per lane and row for both strips: 8 KB per wave), and every three row steps it finishes the candidates of
+// three rows by itself: hand-out among its own lanes through a list in LDS, windows read from the ring (only the
+// two rows just outside a strip, which the stream never loads, come from global memory: a tenth of a window row
+// in six), stage-1 test, and for the keypoints weight and code bytes at once; finished records wait in a small
+// per-wave list and are appended to their frames' tables in batches (table rows reserved with one global atomic
+// per frame and batch, all frames in one instruction).  No workgroup barrier is left in the kernel; 52 KB of LDS
+// per workgroup = three workgroups per CU, which costs the streaming pass nothing (measured with padded LDS).
+#ifndef RMX_BSR_ROWS
+#define RMX_BSR_ROWS 7
 #endif
-constexpr uint32_t KPE_BS_WLIST = 256;  // candidates a wave hands out per round of bs_roll
-
-// stage 1 (is the candidate a keypoint?) for the candidates of the last three row steps of ONE wave, inside the row
-// loop: their 5x5 windows are gathered two to four steps after the stream read those rows, while the lines are
-// still in the L2 (a workgroup that finishes its strips after the walk finds them pushed out by its XCD's other
-// 127 workgroups: 0.04 ms of the kernel).  The wave hands its candidates out densely among its
-// own lanes through a list in LDS; the keypoints' bits are OR-ed into the candidate words the workgroup's finish
-// reads, which then holds keypoints only.
-struct BsRoll {
-  uint32_t (*s_c)[256];
-  const uint32_t* s_f;
-  const uint32_t* s_col;
-  uint32_t* wl;        // this wave's list (KPE_BS_WLIST entries)
-  uint32_t wave_base;  // first thread of the wave
-  uint32_t lane, ya, RA, fallback_f;
+constexpr uint32_t BSR_ROWS = RMX_BSR_ROWS;   // ring rows (>= 7: a roll reads rows k0 - 2 .. k0 + 4)
+constexpr uint32_t BSR_WL = 128;   // candidates a wave hands out per round
+constexpr uint32_t BSR_KP = 64;    // finished records a wave holds before it appends them
+__device__ __forceinline__ uint32_t bsr_slot(int q) {  // ring slot of strip row q (-1 ..)
+  return (uint32_t)(q + 1) % BSR_ROWS;
+}
+struct alignas(16) BsWaveLds {
+  uint32_t ring[BSR_ROWS][64][4];  // [slot][lane]: c0, c1 (strip A), c2, c3 (strip B) of planes_from_bytes
+  uint32_t wl[BSR_WL];             // lane | row (0..2) << 6 | bit << 8
+  uint32_t kp[BSR_KP][6];          // code dwords 0..3, x | y << 16, frame - first frame of the wave
+  uint32_t fcnt[64], fbase[64];
 };
+struct BsWin;
 __device__ __forceinline__ bool bs_is_keypoint(uint32_t x, const CandData& d);
-__device__ __forceinline__ void bs_roll(const KpeParams& p, const BsRoll& R, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t k0) {
+__device__ __forceinline__ void bs_record(uint32_t x, uint32_t y, const CandData& d, uint4& c4);
+
+struct BsRoll {
+  BsWaveLds* L;
+  const uint32_t* s_f;   // the wave's 64 entries
+  const uint32_t* s_col;
+  uint32_t lane, ya, RA, f0;  // f0: first frame of the wave
+  uint32_t nkp;               // records waiting in L->kp (uniform)
+};
+// append the waiting records to their frames' raw tables
+__device__ __forceinline__ void bs_flush(const KpeParams& p, BsRoll& R) {
+  BsWaveLds& L = *R.L;
+  const uint32_t lane = R.lane, n = R.nkp;
+  if (n == 0) return;  // uniform
+  L.fcnt[lane] = 0;
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  uint32_t rank[BSR_KP / 64];
+#pragma unroll
+  for (uint32_t q = 0; q < BSR_KP / 64; ++q) {
+    const uint32_t i = q * 64 + lane;
+    rank[q] = i < n ? atomicAdd(&L.fcnt[L.kp[i][5]], 1u) : 0u;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  {
+    const uint32_t c = L.fcnt[lane];
+    L.fbase[lane] = c ? atomicAdd(&p.kcount[R.f0 + lane], c) : 0u;  // (lanes past the batch's last frame have no records)
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (uint32_t q = 0; q < BSR_KP / 64; ++q) {
+    const uint32_t i = q * 64 + lane;
+    if (i < n) {
+      const uint32_t fr = L.kp[i][5], slot = L.fbase[fr] + rank[q];
+      if (slot < p.kmax) {
+        RawDesc* dd = p.raw + (size_t)(R.f0 + fr) * p.kmax + slot;
+        reinterpret_cast<uint4*>(dd)[0] = make_uint4(L.kp[i][0], L.kp[i][1], L.kp[i][2], L.kp[i][3]);
+        reinterpret_cast<uint4*>(dd)[1] = make_uint4(L.kp[i][4], 0u, 0u, 0u);
+      } else {
+        atomicOr(&p.status[0], 1u);
+      }
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  R.nkp = 0;
+}
+// the candidates of strip rows k0, k0 + 1, k0 + 2 (words w0..w2 of every lane); ring rows k0 - 1 .. k0 + 3 are in LDS
+__device__ __forceinline__ void bs_roll(const KpeParams& p, BsRoll& R, uint32_t w0, uint32_t w1, uint32_t w2, int k0) {
+  BsWaveLds& L = *R.L;
   const uint32_t lane = R.lane;
   const uint32_t c = (uint32_t)(__builtin_popcount(w0) + __builtin_popcount(w1) + __builtin_popcount(w2));
   uint32_t incl = c;
@@ -163,7 +223,7 @@ __device__ __forceinline__ void bs_roll(const KpeParams& p, const BsRoll& R, uin
     if (lane >= (uint32_t)o) incl += t;
   }
   const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-  for (uint32_t r0 = 0; r0 < T; r0 += KPE_BS_WLIST) {  // uniform
+  for (uint32_t r0 = 0; r0 < T; r0 += BSR_WL) {  // uniform
     uint32_t idx = incl - c;
     const uint32_t ws[3] = {w0, w1, w2};
 #pragma unroll
@@ -172,34 +232,70 @@ __device__ __forceinline__ void bs_roll(const KpeParams& p, const BsRoll& R, uin
       while (w) {
         const uint32_t b = (uint32_t)__builtin_ctz(w);
         w &= w - 1;
-        if (idx >= r0 && idx < r0 + KPE_BS_WLIST) R.wl[idx - r0] = lane | j << 6 | b << 8;
+        if (idx >= r0 && idx < r0 + BSR_WL) L.wl[idx - r0] = lane | j << 6 | b << 8;
         ++idx;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    const uint32_t m = min(KPE_BS_WLIST, T - r0);
+    const uint32_t m = min(BSR_WL, T - r0);
     for (uint32_t q0 = 0; q0 < m; q0 += 64) {  // uniform
       const bool act = q0 + lane < m;
-      const uint32_t e = act ? R.wl[q0 + lane] : 0u;
-      const uint32_t owner = R.wave_base + (e & 63u), j = (e >> 6) & 3u, b = e >> 8;
-      const uint32_t x = act ? R.s_col[owner] * 16 + (b & 15u) : 2u;
-      const uint32_t y = act ? R.ya + (b >> 4) * R.RA + k0 + j : 2u;
-      const uint32_t f = act ? R.s_f[owner] : R.fallback_f;
+      const uint32_t e = act ? L.wl[q0 + lane] : (2u << 8);
+      const uint32_t owner = e & 63u, j = (e >> 6) & 3u, b = e >> 8;
+      const uint32_t s = b >> 4, xin = b & 15u;
+      const int rr = k0 + (int)j;  // strip row of the candidate
+      const uint32_t col = act ? R.s_col[owner] : 0u, f = act ? R.s_f[owner] : R.f0;
+      const uint32_t x = col * 16 + xin, y = R.ya + s * R.RA + (uint32_t)rr;
+      // window dwords (four pixels as bytes each): lo holds pixel (x - 2) & ~3, hi the next four
+      const int A = (int)(owner * 4) + (((int)xin - 2) >> 2);  // byte-dword index along the wave's row (>= 0 for a processed pixel)
+      const uint32_t Alo = (uint32_t)max(A, 0), Ahi = min(Alo + 1u, 255u);
+      const uint32_t off_lo = (Alo >> 2) * 4 + 2 * s + ((Alo >> 1) & 1u), sh_lo = 4 * (Alo & 1u);
+      const uint32_t off_hi = (Ahi >> 2) * 4 + 2 * s + ((Ahi >> 1) & 1u), sh_hi = 4 * (Ahi & 1u);
+      const uint32_t* ring = &L.ring[0][0][0];
       CandData d;
-#if defined(RMX_BS_ROLL_NOGATHER)  /* ablation: the roll's loads from one L1-resident window */
-      gather_candidate(p, 2, 2, R.fallback_f, d);
-#else
-      gather_candidate(p, x, y, f, d);
-#endif
-      if (act && bs_is_keypoint(x, d)) atomicOr(&R.s_c[k0 + j][owner], 1u << b);
+      bool outside = false;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        const int wr = rr - 2 + r;  // strip row of this window row: -2 .. RA + 1
+        const uint32_t slot = bsr_slot(wr);
+        d.lo[r] = ring[slot * 256 + off_lo] >> sh_lo;
+        d.hi[r] = ring[slot * 256 + off_hi] >> sh_hi;
+        outside = outside || (act && (wr < -1 || wr > (int)R.RA));
+      }
+      if (__builtin_amdgcn_ballot_w64(outside)) {  // the rows just outside the strip: not streamed, from global memory
+        const uint8_t* base = p.frames + (size_t)f * p.W * p.H + ((x - 2) & ~3u);
+        const int r_out = rr < 2 ? 0 : 4;  // (row -2 is window row 0 of strip row 0, row RA + 1 window row 4 of strip row RA - 1)
+        if (outside) {
+          const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)(y - 2 + r_out) * p.W);
+          if (r_out == 0) d.lo[0] = v.x, d.hi[0] = v.y;
+          else d.lo[4] = v.x, d.hi[4] = v.y;
+        }
+      }
+      const bool kp = act && bs_is_keypoint(x, d);
+      const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
+      if (km) {
+        uint4 c4;
+        bs_record(x, y, d, c4);
+        if (R.nkp + (uint32_t)__builtin_popcountll(km) > BSR_KP) bs_flush(p, R);  // (uniform; the new records are still in registers)
+        if (kp) {
+          uint32_t* rec = L.kp[R.nkp + mbcnt(km)];
+          rec[0] = c4.x, rec[1] = c4.y, rec[2] = c4.z, rec[3] = c4.w;
+          rec[4] = x | y << 16;
+          rec[5] = f - R.f0;
+        }
+        R.nkp += (uint32_t)__builtin_popcountll(km);
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
   }
 }
 
-__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t* s_f, uint32_t* s_col, uint32_t* s_wl) {
+// ROLL: the rolling finish (candidate words stay in registers, s_wave holds the waves' rings and lists); else the
+// candidate words go to s_c for the workgroup's finish
+template <bool ROLL>
+__device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[256], uint32_t* s_f, uint32_t* s_col, BsWaveLds* s_wave) {
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   s_f[threadIdx.x] = 0;  // (written before the walk: nothing but the thread index lives across it)
@@ -298,30 +394,38 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
   nat[0] &= valid, nat[1] &= valid, nat[2] &= valid, nat[3] &= valid;                                      \
   bs::bytes_from_planes(nat, oa4, ob4);
 #endif
-#if RMX_BS_ROLL
   uint32_t cdw[3] = {0, 0, 0};
-  BsRoll roll{s_c, s_f, s_col, s_wl + wv * KPE_BS_WLIST, wv * 64u, lane, (uint32_t)ya, (uint32_t)RA, f0};
-#define RMX_BS_CAND(jj, word) cdw[rr % 3] = (word)
+  BsRoll roll{ROLL ? s_wave + wv : nullptr, s_f + wv * 64u, s_col + wv * 64u, lane, (uint32_t)ya, (uint32_t)RA, f0, 0u};
+  auto ring_write = [&](int q, const BsRaw& w) {  // strip row q (-1 .. RA) of both strips
+    const u32x4 c = {w.a[0] | w.a[1] << 4, w.a[2] | w.a[3] << 4, w.b[0] | w.b[1] << 4, w.b[2] | w.b[3] << 4};
+    *reinterpret_cast<u32x4*>(&roll.L->ring[bsr_slot(q)][lane][0]) = c;
+  };
+  if constexpr (ROLL) {
+    ring_write(-1, w0);
+    ring_write(0, w1);
+  }
+#define RMX_BS_CAND(jj, word)                     \
+  if constexpr (ROLL) cdw[rr % 3] = (word);       \
+  else s_c[jj][threadIdx.x] = (word);
+#define RMX_BS_RING(PF) \
+  if constexpr (ROLL) ring_write(jj + 1, PF);
 #define RMX_BS_ROLLNOW(R) \
-  if ((R) % 3 == 2) bs_roll(p, roll, cdw[0], cdw[1], cdw[2], (uint32_t)(j + (R) - 2));
-#else
-#define RMX_BS_CAND(jj, word) s_c[jj][threadIdx.x] = (word)
-#define RMX_BS_ROLLNOW(R)
-#endif
+  if constexpr (ROLL && (R) % 3 == 0) bs_roll(p, roll, cdw[0], cdw[1], cdw[2], jj - 3);
 #define RMX_BS_STEP(A, B, Cn, PF, R)                                                                       \
   {                                                                                                        \
     const int jj = j + R;                                                                                  \
     constexpr int rr = R;                                                                                  \
     (void)rr;                                                                                              \
     bs_make_row(PF, Cn);                                                                                   \
+    RMX_BS_RING(PF)                                                                                        \
     PF = load_rows(jj + 1 + RMX_BS_DEPTH);                                                                 \
+    RMX_BS_ROLLNOW(R) /* the three rows before this one: their windows' last row is the one just written */ \
     const int oa = ya + jj, ob = yb + jj;                                                                  \
     uint32_t valid = maskx;                                                                                \
     if (!(oa >= 2 && oa + 5 <= H)) valid &= 0xffff0000u; /* processed rows: [2, H-5] (kpe.hpp:268) */      \
     if (!(ob >= 2 && ob + 5 <= H)) valid &= 0x0000ffffu;                                                   \
     uint32_t nr[4], nat[4], oa4[4], ob4[4];                                                                \
     RMX_BS_SELECT(A, B, Cn)                                                                                \
-    RMX_BS_ROLLNOW(R) /* before this step's stores: a wait for the gathers then covers no store younger than a step */ \
     store_rows(oa, ob, oa4, ob4);                                                                          \
   }
   for (int j = 0; j < RA; j += 6) {
@@ -345,6 +449,11 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 #undef RMX_BS_SELECT
 #undef RMX_BS_CAND
 #undef RMX_BS_ROLLNOW
+#undef RMX_BS_RING
+  if constexpr (ROLL) {
+    bs_roll(p, roll, cdw[0], cdw[1], cdw[2], RA - 3);  // the strip's last three rows (RA is a multiple of six)
+    bs_flush(p, roll);
+  }
 }
 
 // ---- finishing the candidates -----------------------------------------------------------------------------
@@ -441,11 +550,42 @@ __device__ __forceinline__ void bs_emit_keypoint(const KpeParams& p, uint32_t x,
   }
 }
 
+// the same, for the rolling finish: the keypoint's 16 code bytes (weight included); the caller appends the record
+__device__ __forceinline__ void bs_record(uint32_t x, uint32_t y, const CandData& d, uint4& c4) {
+  BsWin W;
+  uint32_t v[7];
+  bs_window(d, x, W);
+  bs_ranks(W, v);
+  const uint32_t p1 = (v[2] >> 16) & 0xfu;
+  const uint32_t weight = bs_rank12_is(v, p1) ? 1u : 2u;
+  const uint32_t* w = W.w;
+  const uint32_t* e = W.e;
+  const uint32_t a0 = nib16(w[0]);
+  const uint32_t b2 = (w[1] & 0xfu) | (e[0] << 4);
+  const uint32_t a1 = nib16((w[1] >> 8) | (e[1] << 24));
+  const uint32_t a2 = nib16(w[2]);
+  const uint32_t b7 = (w[3] & 0xfu) | (e[2] << 4);
+  const uint32_t a3 = nib16((w[3] >> 8) | (e[3] << 24));
+  const uint32_t a4 = nib16(w[4]);
+  const uint32_t b12 = weight | (e[4] << 4);
+  (void)y;
+  c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);
+}
 
 // LDS: s_c[ra][256] candidate words (dynamic), then the hand-out tables.
 #ifndef RMX_BS_WAVES
 #define RMX_BS_WAVES 4
 #endif
+#ifndef RMX_BSR_WGS
+#define RMX_BSR_WGS 4
+#endif
+// the whole extraction with the rolling finish: four independent waves, no workgroup barrier
+__global__ __launch_bounds__(256, RMX_BSR_WGS) void kpe_bs_ring(KpeParams p) {
+  __shared__ uint32_t s_f[256], s_col[256];
+  __shared__ BsWaveLds s_wave[4];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.status[15] = 0;  // (keypoints of sampled frames: kpe_table)
+  kpe_bs_body<true>(p, nullptr, s_f, s_col, s_wave);
+}
 __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
   uint32_t(*s_c)[256] = reinterpret_cast<uint32_t(*)[256]>(s_dyn);
@@ -455,11 +595,6 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
   __shared__ uint32_t s_surv[KPE_BS_LIST];  // its keypoints: the same | place among its frame's keypoints of this round << 18
   __shared__ uint32_t s_fcnt[256], s_fbase[256];  // per frame of the workgroup: keypoints of this round, their first table row
   __shared__ uint32_t s_ns;
-#if RMX_BS_ROLL
-  __shared__ uint32_t s_wl[4 * KPE_BS_WLIST];
-#else
-  uint32_t* const s_wl = nullptr;
-#endif
   const uint32_t tid = threadIdx.x;
   const uint32_t RA = p.rows_per_strip;
 #if defined(RMX_BS_STAMP)  /* diagnostic build (tools/bs_stamps.py): phase times of every workgroup, in p.cand */
@@ -471,7 +606,8 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
 #endif
   RMX_STAMP();
   for (uint32_t k = 0; k < RA; ++k) s_c[k][tid] = 0;
-  kpe_bs_body(p, s_c, s_f, s_col, s_wl);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) p.status[15] = 0;
+  kpe_bs_body<false>(p, s_c, s_f, s_col, nullptr);
   RMX_STAMP();  // 1: streamed
 #if defined(RMX_BS_FINPRIO)  /* experiment: the finishing phase issues ahead of other workgroups' streaming waves */
   __builtin_amdgcn_s_setprio(RMX_BS_FINPRIO);
@@ -563,8 +699,7 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
         e[c] = k < m ? s_list[k] : 0xffffffffu;
         x[c] = 2, y[c] = 2, f[c] = fwg;
         if (e[c] != 0xffffffffu) decode(e[c], x[c], y[c], f[c]);
-#if RMX_BS_ROLL  /* the listed candidates ARE the keypoints (bs_roll tested them inside the row loop) */
-#elif defined(RMX_BS_NOGATHER)  /* ablation: the same loads, all from one window (served by the vector L1) */
+#if defined(RMX_BS_NOGATHER)  /* ablation: the same loads, all from one window (served by the vector L1) */
         gather_candidate(p, 2, 2, fwg, d[c]);
 #elif defined(RMX_BS_L2GATHER)  /* ablation: the candidates' own windows, but of the batch's first four frames (L2-resident) */
         gather_candidate(p, x[c], y[c], f[c] & 3u, d[c]);
@@ -575,11 +710,7 @@ __global__ __launch_bounds__(256, RMX_BS_WAVES) void kpe_bs(KpeParams p) {
 #pragma unroll
       for (int c = 0; c < RMX_BS_S1; ++c) {
         if (k0 + 256 * c + (tid & ~63u) >= m) break;  // uniform
-#if RMX_BS_ROLL
-        const bool kp = e[c] != 0xffffffffu;
-#else
         const bool kp = e[c] != 0xffffffffu && bs_is_keypoint(x[c], d[c]);
-#endif
         const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
         if (km) {
           uint32_t base = 0;

@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void kpe_table(TableParams p) {
   uint32_t k = p.kcount[f];
   if (lane == 0) p.knext[f] = 0;
   if (k > p.kmax) k = p.kmax;
+  // keypoints of every 32nd frame, summed: the host's estimate of the stream's density (which finish the next
+  // batch's extraction kernel uses, api.hip); the extraction kernel cleared the word
+  if (lane == 0 && (f & 31u) == 0) atomicAdd(&p.status[15], k);
   const bool mine = p.wave_ok && k <= 256;
   if (lane == 0) p.left[f] = mine ? 0u : 1u;
   if (!mine) return;

@@ -9,14 +9,17 @@ from remap_amd.synth import scroller_v1, upscale2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bs", "bs-halo", "mf"])
+@pytest.fixture(params=["bs", "bs-halo", "ring", "ring-halo", "mf"])
 def kpe_path(request, monkeypatch):
     """The extraction kernels a context may pick (read from the environment when it is created): kpe_bs
     (3x3 pass on bit planes, widths that are multiples of 16; whole image rows per wave, or 62 chunks + 2
-    halo lanes with short strips) and kpe_mf (any width)."""
+    halo lanes with short strips), kpe_bs_ring (the same streaming pass with the finish rolled into the row loop,
+    which a context otherwise picks by the density of the batch before) and kpe_mf (any width)."""
     if request.param == "mf":
         monkeypatch.setenv("RMX_KPE_BS", "0")
-    elif request.param == "bs-halo":
+    else:
+        monkeypatch.setenv("RMX_BS_RING", "1" if request.param.startswith("ring") else "0")
+    if request.param.endswith("-halo"):
         monkeypatch.setenv("RMX_BS_HALO", "1")
         monkeypatch.setenv("RMX_BS_RA", "6")
     return request.param
@@ -179,22 +182,49 @@ def test_kpe_bs_shapes(gpu, kpe_path):
 
 
 def test_kpe_paths_agree_on_a_long_batch(gpu, monkeypatch):
-    """kpe_bs and kpe_mf on 3 001 frames: medians, counts and tables byte for byte (the batch is not a
-    multiple of the three rows a wave holds; dense frames so every workgroup hands out > 2 048 candidates)"""
+    """kpe_bs, kpe_bs_ring and kpe_mf on 3 001 frames: medians, counts and tables byte for byte (the batch is not a
+    multiple of the three rows a wave holds; dense frames so every workgroup hands out > 2 048 candidates and every
+    wave of the ring kernel appends its records in several batches); and a context left to itself picks the ring
+    kernel after a sparse batch, the workgroup finish after a dense one — same bytes either way."""
     import torch
 
     frames, _ = scroller_v1(3001, dens=40)
     d = torch.from_numpy(frames).cuda()
     res = []
-    for mode in ("1", "0"):
-        monkeypatch.setenv("RMX_KPE_BS", mode)
+    for bs, ring in (("1", "0"), ("1", "1"), ("0", "0")):
+        monkeypatch.setenv("RMX_KPE_BS", bs)
+        monkeypatch.setenv("RMX_BS_RING", ring)
         ctx = L.Context(320, 240, kmax=4096)
         med, desc, kc = ctx.kpe(d)
         assert ctx.kpe_status()[0] == 0
         res.append((med.clone(), desc.clone(), kc.clone()))
         ctx.close()
-    assert torch.equal(res[0][0], res[1][0]), "medians differ between kpe_bs and kpe_mf"
-    assert torch.equal(res[0][2], res[1][2]), "keypoint counts differ"
     k = res[0][2].cpu().numpy()
-    a, b = res[0][1].cpu().numpy(), res[1][1].cpu().numpy()
-    assert all(a[i, : k[i]].tobytes() == b[i, : k[i]].tobytes() for i in range(len(k))), "tables differ"
+    a = res[0][1].cpu().numpy()
+    for other, name in ((res[1], "kpe_bs_ring"), (res[2], "kpe_mf")):
+        assert torch.equal(res[0][0], other[0]), f"medians differ between kpe_bs and {name}"
+        assert torch.equal(res[0][2], other[2]), "keypoint counts differ"
+        b = other[1].cpu().numpy()
+        assert all(a[i, : k[i]].tobytes() == b[i, : k[i]].tobytes() for i in range(len(k))), f"tables differ ({name})"
+    # the choice by density (kpe_table samples every 32nd frame's count; read back with the status words)
+    monkeypatch.delenv("RMX_BS_RING")
+    monkeypatch.setenv("RMX_KPE_BS", "1")
+    monkeypatch.setenv("RMX_TIMING", "1")
+    sparse, _ = scroller_v1(640, dens=200)
+    ds = torch.from_numpy(sparse).cuda()
+    ctx = L.Context(320, 240, kmax=4096)
+    ref_sparse = None
+    for blk, want in ((ds, None), (ds, None), (d[:640], None), (d[:640], res[0]), (ds, None)):
+        med, desc, kc = ctx.kpe(blk)
+        assert ctx.kpe_status()[0] == 0  # (brings the density word back: the NEXT batch's kernel is chosen by it)
+        if blk is ds:
+            if ref_sparse is None:
+                ref_sparse = (med.clone(), kc.clone(), desc.clone())
+            else:
+                assert torch.equal(med, ref_sparse[0]) and torch.equal(kc, ref_sparse[1])
+                kk = kc.cpu().numpy()
+                x, y = desc.cpu().numpy(), ref_sparse[2].cpu().numpy()
+                assert all(x[i, : kk[i]].tobytes() == y[i, : kk[i]].tobytes() for i in range(len(kk)))
+        elif want is not None:
+            assert torch.equal(med, want[0][:640]) and torch.equal(kc, want[2][:640])
+    ctx.close()
