@@ -97,7 +97,7 @@ def cpu_baseline(frames_host):
     return port
 
 
-def pmc_file(n_local, dens):
+def pmc_file(n_local, dens, kernel="kpe_bs"):
     """The committed rocprofv3 --pmc summary of the extraction kernel on this same workload
     (profiles/*_pmc_kpe_bs.json, produced by tools/pmc_kpe.sh + tools/pmc_to_json.py: FETCH_SIZE doubled,
     WRITE_SIZE as is — MI355X_MICROARCH.md §HBM).  (None, None) if the workload differs from the profiled
@@ -106,7 +106,7 @@ def pmc_file(n_local, dens):
         return None, None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_kpe_bs.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kernel}.json")))
     if not files:
         return None, None
     try:
@@ -461,7 +461,8 @@ def main():
         # (2*W*H + 18*K) x the frames one launch processes
         alg_bytes = (2.0 * W * H * n_local + 18.0 * ktot) / max(1.0, launches_per_step)
         achieved = alg_bytes / (ms_kpe * 1e-3) / 1e9 if ms_kpe > 0 else 0.0
-        pmc, pmc_src = pmc_file(n_local, args.dens) if launches_per_step == 1 else (None, None)
+        kernel_name = pipe.lanes[0].ctx.kpe_kernel()
+        pmc, pmc_src = pmc_file(n_local, args.dens, kernel_name) if launches_per_step == 1 else (None, None)
         traffic = float(pmc["hbm_bytes_per_launch"]) if pmc else None
         valu = float(pmc["counters_mean_per_launch"]["SQ_INSTS_VALU"]) if pmc else None
         line = {
@@ -490,18 +491,20 @@ def main():
             "frames_per_s_with_blit_one_block_in_flight": n_total * nb1 / dtb_one,
             "frames_per_s_with_blit_and_codec": n_total * nb / dtc,
             "frames_per_s_host_fed": n_total * nh / dth,
-            "kernel_ms": dict(kpe_bs=ms_kpe, **ms_parts),
+            "kernel_ms": dict({kernel_name: ms_kpe}, **ms_parts),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this workload, "
                                             "a committed run: counters cannot be collected from inside the process)") if pmc_src else None,
-                         "kernel": "kpe_bs (whole keypoint extraction: 3x3 rank selection on bit planes, 32 pixels per lane operation, + "
-                                   "5x5 finish of the workgroup's own candidates; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "kernel": kernel_name + " (whole keypoint extraction: 3x3 rank selection on bit planes, 32 pixels per lane operation, + "
+                                   + ("5x5 finish rolled into the row loop, windows from an LDS ring of the streamed rows"
+                                      if kernel_name == "kpe_bs_ring" else "5x5 finish of the workgroup's own candidates")
+                                   + "; descriptor rows are ordered by kpe_table, 0.03 ms)",
                          "measured_in_this_run": ["achieved", "frac", "one_block_in_flight", "previous_kernels", "device_copy_gbs",
                                                   "torch_device_copy_gbs", "algorithmic_bytes_per_launch"],
                          "one_block_in_flight": {"note": "the same kernel with the chip to itself (single stream, the K steps timed again); "
                                                          "with two blocks in flight the small kpm kernels of the previous block run beside it",
-                                                 "kpe_bs_ms": ms_kpe_one,
+                                                 "kernel": al.ctx.kpe_kernel(), "kernel_ms": ms_kpe_one,
                                                  "frac": alg_bytes / (ms_kpe_one * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_kpe_one > 0 else None},
                          "previous_kernels": {"note": "same box, same frames, same algorithmic bytes",
                                               "kpe_mf_ms": ms_kpe_mf,

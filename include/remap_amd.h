@@ -354,6 +354,10 @@ int rmx_debug_umap_order(rmx_ctx* ctx, const uint64_t* hashes, uint32_t n, uint3
 /* Diagnostic hook: copies `bytes` bytes of the keypoint extraction's scratch plane (the candidate plane of
  * kpe_main / kpe_finish; in builds with -DRMX_BS_STAMP the phase time stamps of kpe_bs's workgroups, eight
  * 64-bit words each, tools/bs_stamps.py) to host memory.  Synchronises.  No counterpart in the reference. */
+/* Diagnostics: the extraction kernel the last rmx_kpe_batch of this context launched ("kpe_bs_ring", "kpe_bs",
+ * "kpe_mf", ...): contexts choose by frame width and, between the two finishes of the bit-plane kernel, by the
+ * keypoint density of the batch whose status words they last read. */
+const char* rmx_kpe_kernel(const rmx_ctx* ctx);
 int rmx_debug_kpe_scratch(rmx_ctx* ctx, void* host_dst, size_t bytes);
 /* Diagnostics: the context's 64 device status words (flags, scan carry, launch-set words, and in builds with
  * -DRMX_STATS / -DRMX_KPM_STAMP the matcher's counters and phase times).  Synchronises. */

@@ -52,6 +52,7 @@ struct rmx_ctx {
   // 320x240 frame): chosen when the last batch whose status words came back had at most one keypoint per 256
   // pixels (kpe_table samples every 32nd frame's count into status[15]); RMX_BS_RING=0/1 forces it.
   int bs_ring_forced = -1;
+  const char* kpe_kernel = "";  // the extraction kernel rmx_kpe_batch launched last (rmx_kpe_kernel)
   bool bs_ring = false;
   // rmx_kpm_seq's launch set (KPM_TIER_* bits, kpm.hip).  Adaptive: the first step of the context launches every
   // instance of the build / match chains and learns which found work; later steps launch those only — an instance
@@ -380,6 +381,8 @@ int rmx_sync(rmx_ctx* ctx) {
   return RMX_OK;
 }
 
+const char* rmx_kpe_kernel(const rmx_ctx* ctx) { return ctx ? ctx->kpe_kernel : ""; }
+
 const char* rmx_last_error(const rmx_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 size_t rmx_ctx_workspace_bytes(const rmx_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
 
@@ -589,6 +592,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
         e = pl.v16 ? launch_fused<16, true>(pl, kp, ctx->stream, ctx->lds_fused) : launch_fused<16, false>(pl, kp, ctx->stream, ctx->lds_fused);
     }
     RMX_HIP(e);
+    ctx->kpe_kernel = "kpe_fused";
   }
   // the two-kernel form (RMX_KPE_PAIR) and the sub-batch experiments exist for kpe_main / kpe_finish only
   const bool use_bs = !ctx->fused.ok && ctx->kpe_bs && !overlap && getenv("RMX_KPE_PAIR") == nullptr;
@@ -617,6 +621,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     {
       Timer t(ctx, &ctx->ms_kpe);
       static const size_t pad_lds = getenv("RMX_BS_PADLDS") ? (size_t)atoi(getenv("RMX_BS_PADLDS")) * 1024 : 0;  // experiment: fewer workgroups per CU
+      ctx->kpe_kernel = ring ? "kpe_bs_ring" : "kpe_bs";
       if (ring) hipLaunchKernelGGL(kpe_bs_ring, grid, dim3(256), pad_lds, ctx->stream, p);  // (keeps no candidate words)
       else hipLaunchKernelGGL(kpe_bs, grid, dim3(256), p.rows_per_strip * 256 * sizeof(uint32_t) + pad_lds, ctx->stream, p);
     }
@@ -648,6 +653,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     // one kernel for both halves (kpe_mf) unless asked for the pair (experiments) or the strip is
     // longer than its LDS words hold
     const bool one_kernel = !overlap && rps <= 8 * KPE_WPS_MAX && getenv("RMX_KPE_PAIR") == nullptr;
+    ctx->kpe_kernel = one_kernel ? "kpe_mf" : "kpe_main+kpe_finish";
     {
       Timer t(ctx, &ctx->ms_kpe);
       if (one_kernel) {

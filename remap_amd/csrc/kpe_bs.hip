@@ -255,10 +255,11 @@ __device__ __forceinline__ void bs_roll(const KpeParams& p, BsRoll& R, uint32_t 
       const uint32_t* ring = &L.ring[0][0][0];
       CandData d;
       bool outside = false;
+      const uint32_t slot0 = (uint32_t)(rr + (int)BSR_ROWS - 1) % BSR_ROWS;  // slot of window row 0 (strip row rr - 2)
 #pragma unroll
       for (int r = 0; r < 5; ++r) {
         const int wr = rr - 2 + r;  // strip row of this window row: -2 .. RA + 1
-        const uint32_t slot = bsr_slot(wr);
+        const uint32_t slot = slot0 + (uint32_t)r - (slot0 + (uint32_t)r >= BSR_ROWS ? BSR_ROWS : 0u);
         d.lo[r] = ring[slot * 256 + off_lo] >> sh_lo;
         d.hi[r] = ring[slot * 256 + off_hi] >> sh_hi;
         outside = outside || (act && (wr < -1 || wr > (int)R.RA));

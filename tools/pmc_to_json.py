@@ -12,7 +12,7 @@ for f in glob.glob(root + "/*/runc/*counter_collection.csv"):
         if kern in row["Kernel_Name"]:
             agg[row["Counter_Name"]].append(float(row["Counter_Value"]))
 m = {k: sum(v) / len(v) for k, v in agg.items()}
-res = {"kernel": kern, "launches_sampled": {k: len(v) for k, v in agg.items()}, "counters_mean_per_launch": m}
+res = {"kernel": kern.rstrip("("), "launches_sampled": {k: len(v) for k, v in agg.items()}, "counters_mean_per_launch": m}
 if "FETCH_SIZE" in m and "WRITE_SIZE" in m:
     res["hbm_read_bytes_per_launch"] = 2 * m["FETCH_SIZE"] * 1024
     res["hbm_write_bytes_per_launch"] = m["WRITE_SIZE"] * 1024

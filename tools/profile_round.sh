@@ -14,8 +14,11 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu --no-workloads --headline-only > $OUT/${TAG}_bench_under_rocprof.json 2> $OUT/rocprof.err || tail -5 $OUT/rocprof.err
 find $OUT/stats -name "*kernel_stats.csv" -exec cp {} $OUT/${TAG}_kernel_stats.csv \;
 cd $R
-bash tools/pmc_kpe.sh $TAG > $OUT/pmc.log 2>&1 || tail -5 $OUT/pmc.log
-python3 tools/pmc_to_json.py gpurun_out/pmc_$TAG kpe_bs $OUT/${TAG}_pmc_kpe_bs.json > /dev/null
-rm -rf $OUT/stats gpurun_out/pmc_$TAG
+# the extraction kernel's two finishes (a context picks by density; forced here so each pass profiles one kernel)
+RMX_BS_RING=1 bash tools/pmc_kpe.sh ${TAG}_ring > $OUT/pmc_ring.log 2>&1 || tail -5 $OUT/pmc_ring.log
+python3 tools/pmc_to_json.py gpurun_out/pmc_${TAG}_ring "kpe_bs_ring(" $OUT/${TAG}_pmc_kpe_bs_ring.json > /dev/null
+RMX_BS_RING=0 bash tools/pmc_kpe.sh ${TAG}_wg > $OUT/pmc_wg.log 2>&1 || tail -5 $OUT/pmc_wg.log
+python3 tools/pmc_to_json.py gpurun_out/pmc_${TAG}_wg "kpe_bs(" $OUT/${TAG}_pmc_kpe_bs.json > /dev/null
+rm -rf $OUT/stats gpurun_out/pmc_${TAG}_ring gpurun_out/pmc_${TAG}_wg
 ls -la $OUT
 head -c 1500 $OUT/${TAG}_bench.json
