@@ -35,19 +35,24 @@ __device__ __forceinline__ ScanSeg seg_shfl_up(const ScanSeg& v, int o) {
   return ScanSeg{__shfl_up(v.r, o), __shfl_up(v.x, o), __shfl_up(v.y, o), __shfl_up(v.c, o)};
 }
 
-// One 1024-thread workgroup; the stream is taken in spans of 16 384 frames (16 per thread, held
-// in registers: every frame is loaded once, all loads of a thread in flight together) with the
-// carry handed from span to span.
-constexpr uint32_t SCAN_PER = 16;
+// One workgroup; the stream is taken in spans of SCAN_NT x 16 frames (16 per thread, held in registers: every
+// frame is loaded once, all loads of a thread in flight together) with the carry handed from span to span.
+// 256 threads, not 1 024 (round 3): the kernel runs beside the other lane's extraction kernel, which leaves a CU a
+// wave slot and a few dozen registers per SIMD — a 16-wave workgroup waited ~250 us for a CU to drain, and the
+// whole chain of its lane with it (the kernel trace of the two-lane bench); alone it takes 16 us either way.
+#ifndef RMX_SCAN_NT
+#define RMX_SCAN_NT 256
+#endif
+constexpr uint32_t SCAN_PER = 16, SCAN_NT = RMX_SCAN_NT;
 
-__global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
-  __shared__ ScanSeg s_wave[16];
+__global__ __launch_bounds__(SCAN_NT) void frc_scan(ScanParams p) {
+  __shared__ ScanSeg s_wave[SCAN_NT / 64];
   __shared__ ScanSeg s_carry;
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   if (tid == 0) s_carry = ScanSeg{0, p.carry_in[0], p.carry_in[1], p.carry_in[2]};
-  for (uint32_t base = 0; base < p.n; base += 1024 * SCAN_PER) {
-    const uint32_t span = min(p.n - base, 1024u * SCAN_PER);
-    const uint32_t chunk = (span + 1023) / 1024;  // <= SCAN_PER
+  for (uint32_t base = 0; base < p.n; base += SCAN_NT * SCAN_PER) {
+    const uint32_t span = min(p.n - base, SCAN_NT * SCAN_PER);
+    const uint32_t chunk = (span + SCAN_NT - 1) / SCAN_NT;  // <= SCAN_PER
     const uint32_t i0 = base + min(span, tid * chunk), i1 = base + min(span, tid * chunk + chunk);
     int32_t ddx[SCAN_PER], ddy[SCAN_PER];
     uint32_t brk = 0;  // bit k: frame i0 + k starts a fragment
@@ -75,7 +80,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
           dy += ddy[k];
         }
       }
-    // segmented scan of the 1024 chunk summaries: wave-inclusive by shuffles, the 16 wave
+    // segmented scan of the chunk summaries: wave-inclusive by shuffles, the wave
     // totals by one thread, seeded with the carry
     ScanSeg inc{reset, dx, dy, cnt};
 #pragma unroll
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(1024) void frc_scan(ScanParams p) {
     __syncthreads();
     if (tid == 0) {
       ScanSeg acc = s_carry;
-      for (uint32_t w = 0; w < 16; ++w) {
+      for (uint32_t w = 0; w < SCAN_NT / 64; ++w) {
         const ScanSeg t = s_wave[w];
         s_wave[w] = acc;
         acc = seg_join(acc, t);
