@@ -87,15 +87,22 @@ def test_kpe_640x480_upscaled(gpu, kpe_path):
     check_against_oracle(upscale2(frames), idx=[0, 3])
 
 
-def test_kpe_kmax_overflow_is_reported(gpu):
+def test_kpe_kmax_overflow_is_reported(gpu, kpe_path):
+    """More keypoints than table rows: RMX_ERR_KMAX with the count that is needed (every extraction kernel
+    counts all of a frame's keypoints, whatever it could store), and a context with that many rows takes them."""
     import torch
 
     rng = np.random.default_rng(9)
     frames = rng.integers(0, 16, size=(2, 64, 128), dtype=np.uint8)
+    need = max(O.orc_kpe(f)[2] for f in frames)
     ctx = L.Context(128, 64, kmax=64)
     ctx.kpe(torch.from_numpy(frames).cuda())
     rc, maxk = ctx.kpe_status()
-    assert rc == -3 and maxk > 64
+    assert rc == -3 and maxk == need
+    ctx.close()
+    ctx = L.Context(128, 64, kmax=need)
+    med, desc, kc = ctx.kpe(torch.from_numpy(frames).cuda())
+    assert ctx.kpe_status()[0] == 0 and int(kc.max()) == need
     ctx.close()
 
 
