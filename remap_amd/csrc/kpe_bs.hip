@@ -167,9 +167,14 @@ struct alignas(16) BsWaveLds {
   uint32_t kp[BSR_KP][6];          // code dwords 0..3, x | y << 16, frame - first frame of the wave
   uint32_t fcnt[64], fbase[64];
 };
-struct BsWin;
-__device__ __forceinline__ bool bs_is_keypoint(uint32_t x, const CandData& d);
-__device__ __forceinline__ void bs_record(uint32_t x, uint32_t y, const CandData& d, uint4& c4);
+struct BsWin {
+  uint32_t w[5], e[5];  // natives: pixels x-2 .. x+1 of each row, and pixel x+2
+};
+__device__ __forceinline__ void bs_window(const CandData& d, uint32_t x, BsWin& W);
+__device__ __forceinline__ void bs_ranks(const BsWin& W, uint32_t (&v)[7]);
+__device__ __forceinline__ uint32_t bs_p3(const uint32_t (&v)[7]);
+__device__ __forceinline__ bool bs_rank12_is(const uint32_t (&v)[7], uint32_t t);
+__device__ __forceinline__ void bs_record(const BsWin& W, const uint32_t (&v)[7], uint4& c4);
 
 struct BsRoll {
   BsWaveLds* L;
@@ -280,11 +285,16 @@ __device__ __forceinline__ void bs_roll(const KpeParams& p, BsRoll& R, uint32_t 
           else d.lo[4] = v.x, d.hi[4] = v.y;
         }
       }
-      const bool kp = act && bs_is_keypoint(x, d);
+      // (window and ranks are made once, for the test and for the record)
+      BsWin Wn;
+      uint32_t vr[7];
+      bs_window(d, x, Wn);
+      bs_ranks(Wn, vr);
+      const bool kp = act && !bs_rank12_is(vr, bs_p3(vr));
       const uint64_t km = __builtin_amdgcn_ballot_w64(kp);
       if (km) {
         uint4 c4;
-        bs_record(x, y, d, c4);
+        bs_record(Wn, vr, c4);
         if (R.nkp + (uint32_t)__builtin_popcountll(km) > BSR_KP) bs_flush(p, R);  // (uniform; the new records are still in registers)
         if (kp) {
           uint32_t* rec = L.kp[R.nkp + mbcnt(km)];
@@ -471,9 +481,6 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 // (kpe.hpp:326-340 returns the largest t whose count from the top reaches 12).  So every candidate gets two
 // counts (p3, p3 + 1) instead of kpe.hip's four-step search, and only the survivors (7-18 %) — queued per
 // wave and handled 64 at a time — get two more (p1, p1 + 1), their code bytes and the append.
-struct BsWin {
-  uint32_t w[5], e[5];  // natives: pixels x-2 .. x+1 of each row, and pixel x+2
-};
 __device__ __forceinline__ void bs_window(const CandData& d, uint32_t x, BsWin& W) {
   const uint32_t s = (x - 2) & 3u;
 #pragma unroll
@@ -559,11 +566,7 @@ __device__ __forceinline__ void bs_emit_keypoint(const KpeParams& p, uint32_t x,
 }
 
 // the same, for the rolling finish: the keypoint's 16 code bytes (weight included); the caller appends the record
-__device__ __forceinline__ void bs_record(uint32_t x, uint32_t y, const CandData& d, uint4& c4) {
-  BsWin W;
-  uint32_t v[7];
-  bs_window(d, x, W);
-  bs_ranks(W, v);
+__device__ __forceinline__ void bs_record(const BsWin& W, const uint32_t (&v)[7], uint4& c4) {
   const uint32_t p1 = (v[2] >> 16) & 0xfu;
   const uint32_t weight = bs_rank12_is(v, p1) ? 1u : 2u;
   const uint32_t* w = W.w;
@@ -576,7 +579,6 @@ __device__ __forceinline__ void bs_record(uint32_t x, uint32_t y, const CandData
   const uint32_t a3 = nib16((w[3] >> 8) | (e[3] << 24));
   const uint32_t a4 = nib16(w[4]);
   const uint32_t b12 = weight | (e[4] << 4);
-  (void)y;
   c4 = make_uint4(a0 | b2 << 16 | (a1 & 0xffu) << 24, (a1 >> 8) | a2 << 8 | b7 << 24, a3 | a4 << 16, b12);
 }
 
