@@ -49,7 +49,7 @@ struct rmx_ctx {
   uint32_t bs_ra_ring = 24;    // ... of kpe_bs_ring (its finish does not care how far behind the stream it runs)
   // Which finish the bit-plane extraction kernel uses.  kpe_bs_ring (the finish rolled into the row loop, windows
   // from an LDS ring) is 8 % faster on streams with few keypoints and 20 % slower on dense ones (1 100 per
-  // 320x240 frame): chosen when the last batch whose status words came back had at most one keypoint per 256
+  // 320x240 frame): chosen when the last batch whose status words came back had at most one keypoint per 320
   // pixels (kpe_table samples every 32nd frame's count into status[15]); RMX_BS_RING=0/1 forces it.
   int bs_ring_forced = -1;
   const char* kpe_kernel = "";  // the extraction kernel rmx_kpe_batch launched last (rmx_kpe_kernel)
@@ -348,7 +348,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
 static void kpe_note_density(rmx_ctx* ctx, uint32_t sampled_keypoints) {
   if (ctx->bs_ring_forced >= 0 || ctx->n_last == 0 || ctx->kmax > KPE_KMAX_LDS) return;  // (kpe_table_big does not sample)
   const uint64_t frames = (ctx->n_last + 31) / 32;
-  ctx->bs_ring = (uint64_t)sampled_keypoints * 256 <= frames * ctx->W * ctx->H;
+  ctx->bs_ring = (uint64_t)sampled_keypoints * 320 <= frames * ctx->W * ctx->H;  // (measured crossover at 320x240: between 173 and 360 keypoints per frame)
 }
 
 int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n) {
