@@ -445,11 +445,11 @@ class AlignerPipe:
     """Blocks of a stream in flight on `lanes` Aligners (each with its own HIP stream and
     workspaces), taken in turn.
 
-    A step of the hot path is one VALU-bound kernel (kpe_mf, two thirds of the step) followed by
-    a chain of ~14 small latency-bound ones (table, kpm_build*, kpm_match*, declare, scan) that
-    leave most of the chip idle.  With two lanes the chain of block t runs beside the extraction
-    of block t + 1.  The extraction kernels themselves take turns (an event between the lanes):
-    two of them side by side only share the chip, and each would take twice as long.
+    A step of the hot path is one chip-filling kernel (the extraction: kpe_bs_ring / kpe_bs, four fifths of
+    the step's instructions) followed by a chain of small latency-bound ones (table, kpm_build*, kpm_match*,
+    declare, scan) that leave most of the chip idle.  With two lanes the chain of block t runs beside the
+    extraction of block t + 1.  The extraction kernels themselves take turns (rmx_kpe_take_turns: an event
+    right behind each extraction kernel): two of them side by side only share the chip.
 
     Every block is a step of its own, as with `Aligner.align(defer=True)`: its results are final once it
     has been settled — by `settle(out)`, by its lane's next block, or by `finish()`, which waits for
