@@ -278,11 +278,15 @@ __host__ __device__ inline uint32_t kpm_off_gstart(uint32_t kmax) { return HDR_U
 __host__ __device__ inline uint32_t kpm_off_gfirst(uint32_t kmax) { return HDR_U32 + 8 * kmax + 8; }
 __host__ __device__ inline uint32_t kpm_off_giter(uint32_t kmax) { return HDR_U32 + 12 * kmax + 8; }
 __host__ __device__ inline uint32_t kpm_off_ht(uint32_t kmax) { return HDR_U32 + 16 * kmax + 8; }
-// 16-byte code of every group (by group id): saves the matcher the gfirst -> descriptor-row hops
+// 16-byte code of every group (by group id): saves the matcher the gfirst -> descriptor-row hops.  A code has 13
+// bytes: the last dword carries byte 12 in its low byte and, above it, the low 24 bits of the code's hash
+// (kpr::code_hash), which the builder has at hand — the matcher takes its probe slot from there instead of hashing
+// 13 bytes again per lookup (two records with the same code carry the same bits: comparisons are not affected).
 __host__ __device__ inline uint32_t kpm_off_gcode(uint32_t kmax) { return HDR_U32 + 32 * kmax + 136; }
-__device__ __forceinline__ void store_gcode(uint32_t* pool, uint32_t kmax, uint32_t g, const uint32_t c[4]) {
-  reinterpret_cast<uint4*>(pool + kpm_off_gcode(kmax))[g] = make_uint4(c[0], c[1], c[2], c[3]);
+__device__ __forceinline__ void store_gcode(uint32_t* pool, uint32_t kmax, uint32_t g, const uint32_t c[4], uint32_t hash_lo) {
+  reinterpret_cast<uint4*>(pool + kpm_off_gcode(kmax))[g] = make_uint4(c[0], c[1], c[2], (c[3] & 0xffu) | hash_lo << 8);
 }
+__device__ __forceinline__ uint32_t gcode_hash(const uint32_t c[4]) { return c[3] >> 8; }  // (low 24 bits: masks are <= 2^14)
 __device__ __forceinline__ void load_gcode(const uint32_t* pool, uint32_t kmax, uint32_t g, uint32_t c[4]) {
   const uint4 v = reinterpret_cast<const uint4*>(pool + kpm_off_gcode(kmax))[g];
   c[0] = v.x;
@@ -494,7 +498,7 @@ __device__ __forceinline__ void kpm_build_frame(const KpmBuildParams& p, const u
         uint32_t c[4];
         load_code(desc + ent[first], c);
         hg[gid] = fnv_code(c);
-        store_gcode(pool, p.kmax, g_off + gid, c);
+        store_gcode(pool, p.kmax, g_off + gid, c, (uint32_t)hg[gid]);
         ++gid;
       }
     }
@@ -663,6 +667,7 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   if (threadIdx.x == 0) needs_large[fslot] = 0u;
   // 2. group by code (slot value = smallest entry rank with that code), weights
   uint32_t c[4] = {0, 0, 0, 0}, myslot = 0, w2 = 0, w1 = 0, slots = 16, G = 0, gid = 0, first = 0;
+  uint64_t h64 = 0;
   bool start = false;
   uint32_t key = 0xffffffffu;
   {
@@ -674,7 +679,8 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
     __builtin_amdgcn_wave_barrier();
     if (mine && lane < e) {
       code_of(ent[r][lane], c);
-      uint32_t s = fnv_code_lo(c) & mask;
+      h64 = fnv_code(c);  // (once per entry: its low bits are the slot, a group's first entry hands it to the group)
+      uint32_t s = (uint32_t)h64 & mask;
       for (;;) {
         uint32_t v = atomicCAS(&htl[r][s], EMPTY, lane);
         if (v == EMPTY) break;
@@ -725,6 +731,10 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
   uint32_t* gstart = pool + kpm_off_gstart(p.kmax);
   uint32_t* gfirst = pool + kpm_off_gfirst(p.kmax);
   uint32_t* ght = pool + kpm_off_ht(p.kmax);
+  // the hash of a group's first entry sits in the lane with that entry's rank (same half-wave)
+  const uint32_t src = (threadIdx.x & 63u & ~(LPR - 1u)) + (first & (LPR - 1u));
+  const uint64_t hf = (uint64_t)(uint32_t)__shfl((int)(uint32_t)h64, (int)src) |
+                      (uint64_t)(uint32_t)__shfl((int)(uint32_t)(h64 >> 32), (int)src) << 32;
   if (mine && lane < e) {
     pts[p_off + lane] = s_xy[ent[r][key & 0xffffu]];
     if (start) {
@@ -732,8 +742,8 @@ __device__ __forceinline__ void kpm_build_small_frame(const KpmBuildParams& p, u
       gfirst[g_off + gid] = ent[r][first];
       uint32_t cf[4];
       code_of(ent[r][first], cf);
-      hg[r][gid] = fnv_code(cf);
-      store_gcode(pool, p.kmax, g_off + gid, cf);
+      hg[r][gid] = hf;
+      store_gcode(pool, p.kmax, g_off + gid, cf, (uint32_t)hf);
       gid_of[r][first] = (uint16_t)gid;  // rank of a group's first entry -> group id
     }
   }
@@ -975,7 +985,7 @@ __device__ __forceinline__ void kpm_build_medium_frame(const KpmBuildParams& p, 
       gfirst[g_off + gid] = ent[r][first];
       uint32_t cf[4];
       code_of(row, cf);  // j is the group's first entry
-      store_gcode(pool, p.kmax, g_off + gid, cf);
+      store_gcode(pool, p.kmax, g_off + gid, cf, (uint32_t)hg[r][gid]);
     }
   }
   KPM_STAMP();  // 45: points and groups exported
@@ -1257,7 +1267,7 @@ __global__ __launch_bounds__(64) void kpm_match(KpmMatchParams p) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       pend[u] = pend[u] && (use_all || (c[u][3] & 0xfu) == 2u);
-      sl[u] = fnv_code_lo(c[u]) & pmask;
+      sl[u] = gcode_hash(c[u]) & pmask;
       hit[u] = false;
       gp[u] = 0;
     }
@@ -1566,7 +1576,7 @@ __global__ __launch_bounds__(64) void kpm_match_pair(KpmMatchParams p) {
     for (int u = 0; u < 2; ++u) {
       pend[u] = pend[u] && (hit[u] || (c[u][3] & 0xfu) == 2u);
       hit[u] = false;
-      sl[u] = fnv_code_lo(c[u]) & pmask[u];
+      sl[u] = gcode_hash(c[u]) & pmask[u];
       pv[u] = 0;
     }
     for (;;) {  // probe rounds: the pending lookups of all lanes advance together
