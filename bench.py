@@ -14,11 +14,12 @@ tables and per-frame offsets are all-gathered over RCCL, and the result is the g
 alignment.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     — kpe_bs (the dominant kernel: keypoint extraction — 3x3 pass on bit planes and 5x5
-                 finish in one launch): algorithmic bytes (2*W*H + 18*K per frame) /
-                 its average launch time from HIP events on the launch stream, against the 8 TB/s
-                 HBM peak; `previous_kernels` = kpe_mf (round 2) and the two-kernel form of rounds
-                 1-2a, timed in this run on this box.  Every figure is measured in the run, except
+  roofline     — the extraction kernel (the dominant one: 3x3 pass on bit planes and 5x5 finish in one
+                 launch; kpe_bs_ring on this stream, `roofline.kernel` names the one that ran): algorithmic
+                 bytes (2*W*H + 18*K per frame) / its average launch time from HIP events
+                 on the launch stream, against the 8 TB/s HBM peak; `one_block_in_flight` = the same
+                 kernel with the chip to itself; `previous_kernels` = kpe_mf (round 2) and the two-kernel
+                 form of rounds 1-2a, timed in this run on this box.  Every figure is measured in the run, except
                  `traffic` and `valu_wave_instructions`, which come from the committed rocprofv3 --pmc
                  passes named in `*_source` (counters cannot be read from inside the process);
   workloads    — the other BASELINE.json workloads, timed in this run (value + the extraction kernel's
