@@ -220,7 +220,13 @@ struct BlitParams {
 constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
 // rows of a wave's tile and frames in its pipe (measured: 8 x 2..8 and 4 x 4..8 within 3 %, 16 rows slower);
 // the byte-per-lane kernel for narrow frames holds two frames of 4 rows in registers
-constexpr int BL_ROWS = 8, BL_DEPTH = 4, BL_ROWS_NARROW = 4;
+#ifndef RMX_BL_ROWS
+#define RMX_BL_ROWS 8
+#endif
+#ifndef RMX_BL_DEPTH
+#define RMX_BL_DEPTH 6  // frames in a wave's pipe (4: 0.375 / 4.45 ms per call on the scroller / rooms stream, 6: 0.357 / 4.05, 8: the same, 12: twice as slow)
+#endif
+constexpr int BL_ROWS = RMX_BL_ROWS, BL_DEPTH = RMX_BL_DEPTH, BL_ROWS_NARROW = 4;
 #ifndef RMX_BLIT_SYNC
 #define RMX_BLIT_SYNC 16  // list positions between two barriers of a workgroup's waves (a divisor of 64; 0: none): 2.17 -> 1.43 GB fetched per 10 000 frames, same time (4: also 1.43 GB, +10 % time)
 #endif
