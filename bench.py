@@ -228,6 +228,8 @@ def main():
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU")
     ap.add_argument("--dens", type=int, default=DENS)
     ap.add_argument("--lanes", type=int, default=2, help="blocks in flight (AlignerPipe); 1: one stream")
+    ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps after the W warm-up steps, before the "
+                    "timed region: the device reaches its sustained clocks (0: none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other BASELINE.json workloads (dense, 640x480, rooms)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline's steps (and the one-lane repeat): no tiers B/C, host-fed "
@@ -316,6 +318,17 @@ def main():
     for _ in range(max(args.warmup, 2 * args.lanes)):
         pipe.align(frames, n_total=n_total)
     pipe.finish()
+    # The device needs a few hundred milliseconds of load to reach its sustained state (clocks): the first K steps
+    # after idle run ~8 % slower than every later K steps of the same loop (tools/free_running_frac.py: 0.483 then
+    # 0.441, 0.437 ... ms; after 0.3 s of unrelated matrix products 0.448, 0.437, 0.435).  A stream of blocks runs for
+    # seconds, so the warm-up goes on, untimed, until --spin-up seconds of the same steps have passed.
+    spin_steps = 0
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.spin_up:
+        for _ in range(2 * args.lanes):
+            pipe.align(frames, n_total=n_total)
+        pipe.finish()
+        spin_steps += 2 * args.lanes
     for lane in pipe.lanes:
         lane.ctx.set_timing(2)
     barrier()
@@ -335,6 +348,22 @@ def main():
     launches_per_step = sum(nl) / max(1, args.steps)
     for lane in pipe.lanes:
         lane.ctx.set_timing(False)
+    # ... and with the lanes' extraction kernels free-running (no turns): the faster arrangement, in which a launch's
+    # duration no longer measures the kernel (two of them share the chip) — reported beside the headline
+    dt_free = None
+    if not args.headline_only and args.lanes > 1:
+        pipe.set_turns(False)  # (the same lanes and streams: a fifth stream would share a hardware queue)
+        for _ in range(2 * args.lanes):
+            pipe.align(frames, n_total=n_total)
+        pipe.finish()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            pipe.align(frames, n_total=n_total)
+        pipe.finish()
+        barrier()
+        dt_free = time.perf_counter() - t0
+        pipe.set_turns(True)
     # the same steps on ONE lane (round 2a-2e's figure), for reference.  (Not with --headline-only: the kernel
     # trace of that run then holds the timed region's launches and their warm-up, all in the same regime, and
     # its per-kernel averages are the ones this line reports.)
@@ -451,10 +480,10 @@ def main():
         nb = nb1 = nh = 1
         copy_gbs = torch_copy_gbs = None
 
-    tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0, dt_one, dtb_one], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+    tmax = torch.tensor([dt, dtb, dth, dtc, 0.0 if exact else 1.0, dt_one, dtb_one, dt_free or 0.0], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt, dtb, dth, dtc, bad, dt_one, dtb_one = (float(v) for v in tmax)
+    dt, dtb, dth, dtc, bad, dt_one, dtb_one, dt_free = (float(v) for v in tmax)
     exact = bad == 0.0  # on every rank
 
     if rank == 0:
@@ -487,7 +516,11 @@ def main():
                                       + (f", {args.lanes} blocks in flight per GPU (the small kernels of block t beside the extraction of block t+1)"
                                          if args.lanes > 1 else "")},
             "offsets_bit_exact_vs_truth": exact,
+            "spin_up": {"seconds": args.spin_up, "untimed_steps": spin_steps,
+                        "note": "untimed steps of the same loop between the W warm-up steps and the K timed ones: the device's "
+                                "sustained state (the first K steps after idle run ~8 % slower than all later ones)"},
             "frames_per_s_one_block_in_flight": n_total * args.steps / dt_one,
+            "frames_per_s_extraction_kernels_free_running": (n_total * args.steps / dt_free) if dt_free else None,
             "frames_per_s_with_blit": n_total * nb / dtb,
             "frames_per_s_with_blit_one_block_in_flight": n_total * nb1 / dtb_one,
             "frames_per_s_with_blit_and_codec": n_total * nb / dtc,

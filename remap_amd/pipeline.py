@@ -457,7 +457,7 @@ class AlignerPipe:
     With several ranks the lanes share one process group: its collectives run in issue order,
     which is the same on every rank."""
 
-    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2):
+    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2, turns=True):
         import torch
 
         self.torch = torch
@@ -467,10 +467,22 @@ class AlignerPipe:
         for s in self.streams:
             with torch.cuda.stream(s):  # (a Context adopts the stream that is current when it is made)
                 self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=group))
-        if lanes > 1:
-            L.kpe_take_turns([a.ctx for a in self.lanes])
+        # turns=False leaves the lanes' extraction kernels free-running: they overlap head to tail and the step gets
+        # ~4 % shorter (0.462 against 0.480 ms), but two of them then share the chip for most of their time and a
+        # launch's duration says nothing about the kernel any more — bench.py times the headline with turns and
+        # reports the free-running rate beside it
+        self.set_turns(turns)
         self._turn = 0
         self._pending = [None] * lanes
+
+    def set_turns(self, on):
+        """Extraction kernels of the lanes one after the other (rmx_kpe_take_turns) or free-running."""
+        if len(self.lanes) > 1:
+            if on:
+                L.kpe_take_turns([a.ctx for a in self.lanes])
+            else:
+                for a in self.lanes:
+                    L.kpe_take_turns([a.ctx])  # (a group of one: leaves the group)
 
     def align(self, frames, n_total=None):
         t = self.torch
