@@ -227,7 +227,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="frames per GPU")
     ap.add_argument("--dens", type=int, default=DENS)
-    ap.add_argument("--lanes", type=int, default=2, help="blocks in flight (AlignerPipe); 1: one stream")
+    ap.add_argument("--lanes", type=int, default=3, help="blocks in flight (AlignerPipe); 1: one stream.  Three: a lane's next block is enqueued "
+                    "while its previous chain still runs beside the other lanes' extraction kernels (two: 0.453 ms per step, three: 0.430, four: 0.465)")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps after the W warm-up steps, before the "
                     "timed region: the device reaches its sustained clocks (0: none)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -537,7 +538,7 @@ def main():
                          "measured_in_this_run": ["achieved", "frac", "one_block_in_flight", "previous_kernels", "device_copy_gbs",
                                                   "torch_device_copy_gbs", "algorithmic_bytes_per_launch"],
                          "one_block_in_flight": {"note": "the same kernel with the chip to itself (single stream, the K steps timed again); "
-                                                         "with two blocks in flight the small kpm kernels of the previous block run beside it",
+                                                         "with several blocks in flight the small kpm kernels of the previous blocks run beside it",
                                                  "kernel": al.ctx.kpe_kernel(), "kernel_ms": ms_kpe_one,
                                                  "frac": alg_bytes / (ms_kpe_one * 1e-3) / 1e9 / HBM_PEAK_GBS if ms_kpe_one > 0 else None},
                          "previous_kernels": {"note": "same box, same frames, same algorithmic bytes",
