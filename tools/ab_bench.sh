@@ -4,7 +4,7 @@ cd "$(dirname "$0")/.."
 for cfg in "$@"; do
   IFS='|' read -r name envs so <<< "$cfg"
   echo "== $name"
-  env $envs ${so:+RMX_SO=$PWD/$so} python3 bench.py --steps 20 --warmup 3 --no-cpu --no-workloads --headline-only --lanes ${LANES:-2} 2>/dev/null | python3 -c "
+  env $envs ${so:+RMX_SO=$PWD/$so} python3 bench.py --steps 20 --warmup 3 --no-cpu --no-workloads --headline-only --lanes ${LANES:-3} 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); print(d['ms_per_step'], round(d['value']/1e6,2), round(d['roofline']['achieved']))"
 done
