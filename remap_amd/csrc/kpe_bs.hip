@@ -427,8 +427,12 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
   else s_c[jj][threadIdx.x] = (word);
 #define RMX_BS_RING(PF) \
   if constexpr (ROLL) ring_write(jj + 1, PF);
+#if defined(RMX_BSR_NOROLL)  /* ablation: the streaming pass and the ring writes alone (tools/ab_kpe_bs.sh) */
+#define RMX_BS_ROLLNOW(R)
+#else
 #define RMX_BS_ROLLNOW(R) \
   if constexpr (ROLL && (R) % 3 == 0) bs_roll(p, roll, cdw[0], cdw[1], cdw[2], jj - 3);
+#endif
 #define RMX_BS_STEP(A, B, Cn, PF, R)                                                                       \
   {                                                                                                        \
     const int jj = j + R;                                                                                  \
@@ -468,10 +472,12 @@ __device__ __forceinline__ void kpe_bs_body(const KpeParams& p, uint32_t (*s_c)[
 #undef RMX_BS_CAND
 #undef RMX_BS_ROLLNOW
 #undef RMX_BS_RING
+#if !defined(RMX_BSR_NOROLL)
   if constexpr (ROLL) {
     bs_roll(p, roll, cdw[0], cdw[1], cdw[2], RA - 3);  // the strip's last three rows (RA is a multiple of six)
     bs_flush(p, roll);
   }
+#endif
 }
 
 // ---- finishing the candidates -----------------------------------------------------------------------------

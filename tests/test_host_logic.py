@@ -204,3 +204,36 @@ def test_canvas_boxes_equal_the_frame_by_frame_growth():
         ends = list(starts[1:]) + [len(pos)]
         for i, (a, b) in enumerate(zip(starts, ends)):
             assert O.orc_fgm_extent(pos[a:b].astype(np.int32), W, H) == (gw[i], gh[i], zx[i], zy[i])
+
+
+def test_pairwise_candidate_test_matches_oracle(tmp_path):
+    """remap_amd/csrc/paircmp.h (the arithmetic of kpe_pc.hip: a pixel is a candidate unless at most three of its
+    eight neighbours are greater and at least three are greater or equal — rank comparisons of adjacent pixels on
+    bit planes, each shared by the two windows it belongs to) compiled for the host and run in the kernel's
+    arrangement (tests/cpp/paircmp_check.cpp) against the oracle's kpe (reference kpe.hpp:308-340): candidates =
+    the processed pixels whose median differs from the input, whatever the lanes at a row's ends receive."""
+    import ctypes
+    import subprocess
+
+    import orclib as O
+    from remap_amd.synth import scroller_v1
+
+    so = tmp_path / "libpaircmp_check.so"
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", str(so),
+                           os.path.join(ROOT, "tests", "cpp", "paircmp_check.cpp")])
+    lib = ctypes.CDLL(str(so))
+    lib.pc_kpe_cand.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]
+    rng = np.random.default_rng(1)
+    frames, _ = scroller_v1(3, dens=40)
+    cases = [frames[0], frames[2], rng.integers(0, 16, (240, 320), dtype=np.uint8), rng.integers(0, 16, (48, 64), dtype=np.uint8),
+             rng.integers(0, 3, (64, 32), dtype=np.uint8) * 5, np.zeros((16, 32), np.uint8)]
+    for fr in cases:
+        fr = np.ascontiguousarray(fr)
+        Hh, Ww = fr.shape
+        omed = O.orc_kpe(fr, 1, 1, 0)[0]
+        inner = np.zeros((Hh, Ww), bool)
+        inner[2:Hh - 4, 2:Ww - 2] = True
+        for junk in (0, 0xffffffff, 0x5a5a1234):
+            cand = np.zeros((Hh, Ww), np.uint8)
+            assert lib.pc_kpe_cand(fr.ctypes.data, Ww, Hh, cand.ctypes.data, junk) == 0
+            assert np.array_equal(cand.astype(bool), (omed != fr) & inner)
