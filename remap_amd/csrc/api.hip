@@ -15,6 +15,7 @@
 #include "common.h"
 #include "kpe.hip"
 #include "kpe_bs.hip"
+#include "kpe_pc.hip"
 #include "kpe_fused.hip"
 #include "table.hip"
 #include "kpm.hip"
@@ -52,6 +53,13 @@ struct rmx_ctx {
   // 320x240 frame): chosen when the last batch whose status words came back had at most one keypoint per 320
   // pixels (kpe_table samples every 32nd frame's count into status[15]); RMX_BS_RING=0/1 forces it.
   int bs_ring_forced = -1;
+  // kpe_pc (kpe_pc.hip: candidate test by pairwise comparison, medians patched in the LDS ring) takes the ring
+  // kernel's place where a frame's rows fill a wave: widths that are multiples of 32 whose 32-pixel chunks divide
+  // 64 with at most eight lanes idle.  RMX_KPE_PC=0: kpe_bs_ring.  pc_ra: rows per strip (one strip per wave).
+  bool kpe_pc = false;
+  uint32_t pc_ra = 30;
+  uint32_t* pc_ovf = nullptr;  // PC_OVF_DWORDS per wave of the launch, all zero between launches
+  size_t pc_ovf_bytes = 0;
   const char* kpe_kernel = "";  // the extraction kernel rmx_kpe_batch launched last (rmx_kpe_kernel)
   bool bs_ring = false;
   // rmx_kpm_seq's launch set (KPM_TIER_* bits, kpm.hip).  Adaptive: the first step of the context launches every
@@ -306,6 +314,9 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_KPE_BS")) ctx->kpe_bs = ctx->kpe_bs && atoi(e) != 0;
   if (const char* e = getenv("RMX_BS_RA")) ctx->bs_ra = ctx->bs_ra_ring = (uint32_t)std::min<int>(std::max(1, atoi(e)), (int)KPE_BS_RA_MAX);
   if (const char* e = getenv("RMX_BS_RING")) ctx->bs_ring_forced = atoi(e) != 0, ctx->bs_ring = atoi(e) != 0;
+  ctx->kpe_pc = ctx->kpe_bs && width % 32 == 0 && width / 32 <= 64 && 64 % (width / 32) <= 8;
+  if (const char* e = getenv("RMX_KPE_PC")) ctx->kpe_pc = ctx->kpe_pc && atoi(e) != 0;
+  if (const char* e = getenv("RMX_PC_RA")) ctx->pc_ra = (uint32_t)std::max(6, atoi(e) / 6 * 6);
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
@@ -325,6 +336,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->tflag) (void)hipFree(ctx->tflag);
   if (ctx->kraw_base) (void)hipFree(ctx->kraw_base);
   if (ctx->cand) (void)hipFree(ctx->cand);
+  if (ctx->pc_ovf) (void)hipFree(ctx->pc_ovf);
   if (ctx->tab_ws) (void)hipFree(ctx->tab_ws);
   if (ctx->status) (void)hipFree(ctx->status);
   if (ctx->host_words) (void)hipHostFree(ctx->host_words);
@@ -596,7 +608,44 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   }
   // the two-kernel form (RMX_KPE_PAIR) and the sub-batch experiments exist for kpe_main / kpe_finish only
   const bool use_bs = !ctx->fused.ok && ctx->kpe_bs && !overlap && getenv("RMX_KPE_PAIR") == nullptr;
-  if (use_bs) {
+  const bool use_pc = use_bs && ctx->bs_ring && ctx->kpe_pc;
+  if (use_pc) {
+    KpeParams p{};
+    p.frames = frames;
+    p.median = median;
+    p.raw = ctx->raw;
+    p.kcount = ctx->kraw;
+    p.status = ctx->status;
+    p.n = n;
+    p.W = ctx->W;
+    p.H = ctx->H;
+    p.Wd = ctx->W / 32;  // 32-pixel chunks per row
+    p.HB = 64 / p.Wd;    // image rows (of consecutive frames) per wave
+    p.groups = (n + p.HB - 1) / p.HB;
+    p.V = (uint64_t)n * p.Wd;
+    p.rows_per_strip = std::max(6u, std::min(ctx->pc_ra, (ctx->H + 5) / 6 * 6) / 6 * 6);
+    p.kmax = ctx->kmax;
+    dim3 grid((p.groups + 3) / 4, (ctx->H + p.rows_per_strip - 1) / p.rows_per_strip);
+    const size_t ovf_bytes = (size_t)grid.x * grid.y * 4 * PC_OVF_DWORDS * sizeof(uint32_t);
+    if (ovf_bytes > ctx->pc_ovf_bytes) {  // (the kernel leaves it as it finds it: all zero)
+      if (ctx->pc_ovf) {
+        RMX_HIP(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->pc_ovf);
+        ctx->pc_ovf = nullptr, ctx->pc_ovf_bytes = 0;
+      }
+      RMX_HIP(hipMalloc(&ctx->pc_ovf, ovf_bytes));
+      RMX_HIP(hipMemsetAsync(ctx->pc_ovf, 0, ovf_bytes, ctx->stream));
+      ctx->pc_ovf_bytes = ovf_bytes;
+    }
+    p.cand = ctx->pc_ovf;
+    {
+      Timer t(ctx, &ctx->ms_kpe);
+      ctx->kpe_kernel = "kpe_pc";
+      hipLaunchKernelGGL(kpe_pc, grid, dim3(256), 0, ctx->stream, p);
+    }
+    RMX_HIP(hipGetLastError());
+  }
+  if (use_bs && !use_pc) {
     KpeParams p{};
     p.frames = frames;
     p.median = median;

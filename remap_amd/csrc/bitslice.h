@@ -73,13 +73,13 @@ RMX_HD void delta_swap(uint32_t& x, uint32_t& y, uint32_t s, uint32_t mask) {
 
 // a[0..3]: the 16 pixels of strip A (one 0..15 value per byte, pixel 4k + j in byte j of a[k]), b[0..3]:
 // strip B.  n[q]: plane of bit q of the values, bit 16 s + x = pixel x of strip s.
-// 4 shift-or + 8 byte permutes + 4 delta swaps (6 ops each) = 36 operations for 32 pixels.
-RMX_HD void planes_from_bytes(const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&n)[4]) {
-  // two pixels per byte: dword (s, k1) holds pixels 8 k1 + 4 k0 + j at bit 8 j + 4 k0 + q
-  const uint32_t c0 = a[0] | a[1] << 4, c1 = a[2] | a[3] << 4, c2 = b[0] | b[1] << 4, c3 = b[2] | b[3] << 4;
+// 4 shift-or + 8 byte permutes + 4 delta swaps (6 ops each) = 36 operations for 32 pixels (planes_from_packed:
+// without the first four, for rows that are already two pixels per byte).
+RMX_HD void planes_from_packed(const uint32_t (&c)[4], uint32_t (&n)[4]) {
+  // c[k1] (k1 = 0, 1: strip A, 2, 3: strip B): pixels 8 k1 + 4 k0 + j of the 32 at bit 8 j + 4 k0 + q
   // 4 x 4 byte transpose: e_j byte i = byte j of c_i
-  const uint32_t u0 = byte_perm(c1, c0, 0x05010400u), u1 = byte_perm(c1, c0, 0x07030602u);
-  const uint32_t u2 = byte_perm(c3, c2, 0x05010400u), u3 = byte_perm(c3, c2, 0x07030602u);
+  const uint32_t u0 = byte_perm(c[1], c[0], 0x05010400u), u1 = byte_perm(c[1], c[0], 0x07030602u);
+  const uint32_t u2 = byte_perm(c[3], c[2], 0x05010400u), u3 = byte_perm(c[3], c[2], 0x07030602u);
   uint32_t e0 = byte_perm(u2, u0, 0x05040100u), e1 = byte_perm(u2, u0, 0x07060302u);
   uint32_t e2 = byte_perm(u3, u1, 0x05040100u), e3 = byte_perm(u3, u1, 0x07060302u);
   // e_j: bit 8 i + 4 k0 + q, i = (s, k1).  Exchange the dword index j with the bit index q.
@@ -88,6 +88,11 @@ RMX_HD void planes_from_bytes(const uint32_t (&a)[4], const uint32_t (&b)[4], ui
   delta_swap(e0, e2, 2, 0x33333333u);
   delta_swap(e1, e3, 2, 0x33333333u);
   n[0] = e0, n[1] = e1, n[2] = e2, n[3] = e3;
+}
+RMX_HD void planes_from_bytes(const uint32_t (&a)[4], const uint32_t (&b)[4], uint32_t (&n)[4]) {
+  // two pixels per byte: dword (s, k1) holds pixels 8 k1 + 4 k0 + j at bit 8 j + 4 k0 + q
+  const uint32_t c[4] = {a[0] | a[1] << 4, a[2] | a[3] << 4, b[0] | b[1] << 4, b[2] | b[3] << 4};
+  planes_from_packed(c, n);
 }
 
 // the inverse: 44 operations for 32 pixels
