@@ -49,6 +49,16 @@ DENS = 200
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+KERNEL_NOTES = {
+    "kpe_pc": "candidate test by pairwise rank comparison on bit planes, 32 pixels per lane operation; 5x5 finish rolled into the row "
+              "loop, windows from an LDS ring of the streamed rows; the median plane = the input rows from that ring with the "
+              "candidates' nibbles patched",
+    "kpe_bs_ring": "3x3 rank selection on bit planes, 32 pixels per lane operation, + 5x5 finish rolled into the row loop, windows "
+                   "from an LDS ring of the streamed rows",
+    "kpe_bs": "3x3 rank selection on bit planes, 32 pixels per lane operation, + 5x5 finish of the workgroup's own candidates",
+}
+
+
 def cpu_baseline(frames_host):
     """Reference (or port) CPU path on one host core over `frames_host`.
 
@@ -231,6 +241,8 @@ def main():
                     "while its previous chain still runs beside the other lanes' extraction kernels (two: 0.453 ms per step, three: 0.430, four: 0.465)")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps after the W warm-up steps, before the "
                     "timed region: the device reaches its sustained clocks (0: none)")
+    ap.add_argument("--sustain", type=float, default=1.0, help="seconds of further K-step groups after the timed one, reported as "
+                    "`sustained` (median / min / max per group); 0: none")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-workloads", action="store_true", help="skip the other BASELINE.json workloads (dense, 640x480, rooms)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline's steps (and the one-lane repeat): no tiers B/C, host-fed "
@@ -347,6 +359,40 @@ def main():
     nl = [lane.ctx.kernel_launches("kpe_main") for lane in pipe.lanes]
     ms_kpe = sum(lane.ctx.kernel_ms("kpe_main") * k for lane, k in zip(pipe.lanes, nl) if k) / max(1, sum(nl))
     launches_per_step = sum(nl) / max(1, args.steps)
+    # The same K-step groups again, back to back for --sustain seconds: the headline above is one group (the driver's
+    # K and W), a few milliseconds long; this says what a stream of blocks sees over a second — median / min / max per
+    # group, the extraction kernel's HIP-event time over all of them.
+    sustained = None
+    if args.sustain > 0:
+        ngroups = int(min(400, max(3, args.sustain / max(dt, 1e-6) + 1)))
+        if dist is not None:
+            g = torch.tensor([ngroups], dtype=torch.int64, device=dev if args.backend != "gloo" else "cpu")
+            dist.all_reduce(g, op=dist.ReduceOp.MAX)
+            ngroups = int(g.item())
+        for lane in pipe.lanes:
+            lane.ctx.set_timing(2)
+        gt = []
+        for _ in range(ngroups):
+            barrier()
+            tg = time.perf_counter()
+            for _ in range(args.steps):
+                pipe.align(frames, n_total=n_total)
+            pipe.finish()
+            barrier()
+            gt.append(time.perf_counter() - tg)
+        nls = [lane.ctx.kernel_launches("kpe_main") for lane in pipe.lanes]
+        ms_kpe_s = sum(lane.ctx.kernel_ms("kpe_main") * k for lane, k in zip(pipe.lanes, nls) if k) / max(1, sum(nls))
+        gtt = torch.tensor(gt, dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+        if dist is not None:
+            dist.all_reduce(gtt, op=dist.ReduceOp.MAX)
+        gt = sorted(float(v) for v in gtt)
+        med = gt[len(gt) // 2]
+        sustained = {"groups": ngroups, "steps_per_group": args.steps, "seconds": sum(gt),
+                     "ms_per_step_median": med / args.steps * 1e3, "ms_per_step_min": gt[0] / args.steps * 1e3,
+                     "ms_per_step_max": gt[-1] / args.steps * 1e3, "value_median": n_total * args.steps / med,
+                     "kernel_ms": ms_kpe_s, "launches": int(sum(nls)),
+                     "note": "the timed region repeated (barrier + synchronize around every group of K steps, max over ranks); "
+                             "`value` above is ONE such group, as the driver's contract asks"}
     for lane in pipe.lanes:
         lane.ctx.set_timing(False)
     # ... and with the lanes' extraction kernels free-running (no turns): the faster arrangement, in which a launch's
@@ -520,6 +566,8 @@ def main():
             "spin_up": {"seconds": args.spin_up, "untimed_steps": spin_steps,
                         "note": "untimed steps of the same loop between the W warm-up steps and the K timed ones: the device's "
                                 "sustained state (the first K steps after idle run ~8 % slower than all later ones)"},
+            "sustained": (dict(sustained, roofline_frac=alg_bytes / (sustained["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+                               if sustained["kernel_ms"] > 0 else None) if sustained else None),
             "frames_per_s_one_block_in_flight": n_total * args.steps / dt_one,
             "frames_per_s_extraction_kernels_free_running": (n_total * args.steps / dt_free) if dt_free else None,
             "frames_per_s_with_blit": n_total * nb / dtb,
@@ -531,10 +579,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (pmc_src + " (rocprofv3 --pmc FETCH_SIZE x 2 + WRITE_SIZE of this kernel on this workload, "
                                             "a committed run: counters cannot be collected from inside the process)") if pmc_src else None,
-                         "kernel": kernel_name + " (whole keypoint extraction: 3x3 rank selection on bit planes, 32 pixels per lane operation, + "
-                                   + ("5x5 finish rolled into the row loop, windows from an LDS ring of the streamed rows"
-                                      if kernel_name == "kpe_bs_ring" else "5x5 finish of the workgroup's own candidates")
-                                   + "; descriptor rows are ordered by kpe_table, 0.03 ms)",
+                         "kernel": kernel_name + " (whole keypoint extraction: " + KERNEL_NOTES.get(kernel_name, "") + "; descriptor rows are ordered by kpe_table, 0.03 ms)",
                          "measured_in_this_run": ["achieved", "frac", "one_block_in_flight", "previous_kernels", "device_copy_gbs",
                                                   "torch_device_copy_gbs", "algorithmic_bytes_per_launch"],
                          "one_block_in_flight": {"note": "the same kernel with the chip to itself (single stream, the K steps timed again); "

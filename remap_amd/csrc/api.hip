@@ -57,7 +57,7 @@ struct rmx_ctx {
   // kernel's place where a frame's rows fill a wave: widths that are multiples of 32 whose 32-pixel chunks divide
   // 64 with at most eight lanes idle.  RMX_KPE_PC=0: kpe_bs_ring.  pc_ra: rows per strip (one strip per wave).
   bool kpe_pc = false;
-  uint32_t pc_ra = 30;
+  uint32_t pc_ra = 30, pc_ra_short = 30, pc_long_pct = 0;  // RMX_PC_PLAN=long,short,percent
   uint32_t* pc_ovf = nullptr;  // PC_OVF_DWORDS per wave of the launch, all zero between launches
   size_t pc_ovf_bytes = 0;
   const char* kpe_kernel = "";  // the extraction kernel rmx_kpe_batch launched last (rmx_kpe_kernel)
@@ -316,7 +316,11 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_BS_RING")) ctx->bs_ring_forced = atoi(e) != 0, ctx->bs_ring = atoi(e) != 0;
   ctx->kpe_pc = ctx->kpe_bs && width % 32 == 0 && width / 32 <= 64 && 64 % (width / 32) <= 8;
   if (const char* e = getenv("RMX_KPE_PC")) ctx->kpe_pc = ctx->kpe_pc && atoi(e) != 0;
-  if (const char* e = getenv("RMX_PC_RA")) ctx->pc_ra = (uint32_t)std::max(6, atoi(e) / 6 * 6);
+  if (const char* e = getenv("RMX_PC_RA")) ctx->pc_ra = ctx->pc_ra_short = (uint32_t)std::max(6, atoi(e) / 6 * 6);
+  if (const char* e = getenv("RMX_PC_PLAN")) {
+    unsigned a = 0, b = 0, c = 0;
+    if (sscanf(e, "%u,%u,%u", &a, &b, &c) == 3 && a >= 6 && b >= 6 && c <= 100) ctx->pc_ra = a / 6 * 6, ctx->pc_ra_short = b / 6 * 6, ctx->pc_long_pct = c;
+  }
   if (hipSetDevice(device) != hipSuccess || hipMalloc(&ctx->status, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
@@ -360,7 +364,8 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
 static void kpe_note_density(rmx_ctx* ctx, uint32_t sampled_keypoints) {
   if (ctx->bs_ring_forced >= 0 || ctx->n_last == 0 || ctx->kmax > KPE_KMAX_LDS) return;  // (kpe_table_big does not sample)
   const uint64_t frames = (ctx->n_last + 31) / 32;
-  ctx->bs_ring = (uint64_t)sampled_keypoints * 320 <= frames * ctx->W * ctx->H;  // (measured crossover at 320x240: between 173 and 360 keypoints per frame)
+  // (measured crossover at 320x240: kpe_bs_ring between 173 and 360 keypoints per frame; kpe_pc: +20 % at 170, -3 % at 450, -45 % at 1 100)
+  ctx->bs_ring = (uint64_t)sampled_keypoints * (ctx->kpe_pc ? 200 : 320) <= frames * ctx->W * ctx->H;
 }
 
 int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n) {
@@ -624,8 +629,12 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     p.groups = (n + p.HB - 1) / p.HB;
     p.V = (uint64_t)n * p.Wd;
     p.rows_per_strip = std::max(6u, std::min(ctx->pc_ra, (ctx->H + 5) / 6 * 6) / 6 * 6);
+    p.rows_short = std::max(6u, std::min(ctx->pc_ra_short, p.rows_per_strip) / 6 * 6);
+    // long strips over the first pc_long_pct % of the rows (fewer halo rows), short ones over the rest
+    p.strips_long = p.rows_short == p.rows_per_strip ? 0u : (uint32_t)((uint64_t)ctx->H * ctx->pc_long_pct / 100 / p.rows_per_strip);
+    const uint32_t rest = ctx->H - p.strips_long * p.rows_per_strip;
     p.kmax = ctx->kmax;
-    dim3 grid((p.groups + 3) / 4, (ctx->H + p.rows_per_strip - 1) / p.rows_per_strip);
+    dim3 grid((p.groups + 3) / 4, p.strips_long + (rest + p.rows_short - 1) / p.rows_short);
     const size_t ovf_bytes = (size_t)grid.x * grid.y * 4 * PC_OVF_DWORDS * sizeof(uint32_t);
     if (ovf_bytes > ctx->pc_ovf_bytes) {  // (the kernel leaves it as it finds it: all zero)
       if (ctx->pc_ovf) {

@@ -53,6 +53,7 @@ struct KpeParams {
   uint32_t kmax;
   uint32_t* cand;    // candidate bit plane: n * HB * Wd dwords
   uint32_t HB;       // ceil(H / 8)
+  uint32_t strips_long, rows_short;  // kpe_pc: the first strips_long strips have rows_per_strip rows, the others rows_short
 };
 
 #ifndef RMX_XLANE_SHFL

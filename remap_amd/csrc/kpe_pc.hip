@@ -115,9 +115,10 @@ struct PcRoll {
   uint32_t* ovf;  // this wave's PC_OVF_DWORDS of global memory (all zero between launches)
   uint32_t lane, ya, RA, f0, Wc, magic;  // magic: lane / Wc == lane * magic >> 16
   uint32_t st_a, st_b;                   // lane offsets of the two median stores of a row (out of range for idle chunks)
-  uint32_t ma0, ma3, mb0, mb3;           // byte masks of their first / last four pixels (x < 2, x > W - 3 are not processed)
+  uint32_t ma0, ma3, mb0, mb3;           // nibble masks of their first / last four pixels (x < 2, x > W - 3 are not processed)
   uint32_t nst;                          // keypoints in the stash (uniform)
   uint32_t cur[PC_REG_PASSES], prev[PC_REG_PASSES];  // patches: owner | row << 6 | bit << 8 | delta << 13 | 1 << 31
+  uint32_t nprev;                        // (uniform) how many of prev[] the roll before filled
   uint32_t ovf_cur, ovf_prev, gen;       // (uniform) patches of that roll in the global buffer; its half
 };
 
@@ -175,11 +176,13 @@ __device__ __forceinline__ void pc_patch(PcWaveLds& L, uint32_t e, uint32_t slot
 // one ring row (final: every patch applied) -> the median plane
 __device__ __forceinline__ void pc_store_row(const KpeParams& p, const PcRoll& R, const rsrc_t& rout, uint32_t slot, int y) {
   const uint32_t* row = &R.L->ring[slot][0][0];
-  const uint2 ca = *reinterpret_cast<const uint2*>(row + 2 * R.lane), cb = *reinterpret_cast<const uint2*>(row + 128 + 2 * R.lane);
-  const bool rowok = y >= 2 && y + 5 <= (int)p.H;  // processed rows: [2, H-5] (kpe.hpp:268); the others are zero
-  const uint32_t m = rowok ? 0x0f0f0f0fu : 0u;
-  const u32x4 va = {ca.x & (m & R.ma0), (ca.x >> 4) & m, ca.y & m, (ca.y >> 4) & (m & R.ma3)};
-  const u32x4 vb = {cb.x & (m & R.mb0), (cb.x >> 4) & m, cb.y & m, (cb.y >> 4) & (m & R.mb3)};
+  u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
+  if (y >= 2 && y + 5 <= (int)p.H) {  // (uniform) processed rows: [2, H-5] (kpe.hpp:268); the others are zero
+    const uint2 ca = *reinterpret_cast<const uint2*>(row + 2 * R.lane), cb = *reinterpret_cast<const uint2*>(row + 128 + 2 * R.lane);
+    const uint32_t m = 0x0f0f0f0fu;
+    va = u32x4{ca.x & R.ma0, (ca.x >> 4) & m, ca.y & m, (ca.y >> 4) & R.ma3};
+    vb = u32x4{cb.x & R.mb0, (cb.x >> 4) & m, cb.y & m, (cb.y >> 4) & R.mb3};
+  }
   const uint32_t voa = y < (int)p.H ? R.st_a : 0x80000000u, vob = y < (int)p.H ? R.st_b : 0x80000000u;
   // (as in kpe_bs: nothing may be scheduled between a 16-byte store and the wait states behind it)
   __builtin_amdgcn_sched_barrier(0);
@@ -205,8 +208,11 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
     if (T > 64 * PC_REG_PASSES) atomicAdd(&p.status[43], 1u);
   }
 #endif
+  // ring rows k0 - 2 + m, m = 0 .. 6, as dword offsets into the ring (uniform): a candidate of row k0 + j reads rows j .. j + 4
+  uint32_t S[7];
 #pragma unroll
-  for (uint32_t q = 0; q < PC_REG_PASSES; ++q) R.cur[q] = 0;
+  for (int m = 0; m < 7; ++m) S[m] = pc_slot(k0 - 2 + m) * 256u;
+  const bool edge = k0 == 0 || k0 + 3 >= (int)R.RA;  // (uniform) rolls whose windows reach past the rows the strip streams
   R.ovf_cur = 0;
   for (uint32_t r0 = 0; r0 < T; r0 += 64) {  // uniform
     // ---- hand-out: place r0 + lane takes the k-th candidate of its owner
@@ -225,45 +231,52 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
     const bool act = r0 + lane < T;
     uint32_t k = r0 + lane - eo;
     const uint32_t c0 = (uint32_t)__builtin_popcount(a0), c01 = c0 + (uint32_t)__builtin_popcount(a1);
-    const uint32_t j = (k >= c0 ? 1u : 0u) + (k >= c01 ? 1u : 0u);
-    uint32_t w = j == 0 ? a0 : (j == 1 ? a1 : a2);
-    k -= j == 0 ? 0u : (j == 1 ? c0 : c01);
+    const bool j1 = k >= c0, j2 = k >= c01;  // the candidate's row of the roll: j = j1 + j2
+    uint32_t w = j2 ? a2 : (j1 ? a1 : a0);
+    k -= j2 ? c01 : (j1 ? c0 : 0u);
     if (!act) w = 4u, k = 0;  // (a harmless place: pixel 2 of the owner's chunk)
     for (uint32_t t = 0; __builtin_amdgcn_ballot_w64(k > t); ++t)  // uniform; k is a handful at most
       if (k > t) w &= w - 1u;
     const uint32_t b = (uint32_t)__builtin_ctz(w);
-    // ---- the 5x5 window from the ring
-    const int rr = k0 + (int)j;  // strip row of the candidate
-    const uint32_t fr = (owner * R.magic) >> 16, col = owner - fr * R.Wc;
-    const uint32_t x = col * 32 + b, y = R.ya + (uint32_t)rr;
+    // ---- the 5x5 window from the ring: per window row the two dwords (sixteen pixels, two per byte) around pixel x - 2
     const int A = (int)(owner * 8) + (((int)b - 2) >> 2);  // byte-dword (four pixels) along the wave's row that holds pixel x - 2
-    const uint32_t Au = (uint32_t)max(A, 0), D = Au >> 1, odd = Au & 1u;
-    const uint32_t sh_lo = 4u * odd, sh_hi = 4u - sh_lo;
+    const uint32_t Au = (uint32_t)max(A, 0), D = Au >> 1;
+    const bool odd = (Au & 1u) != 0;
+    const uint32_t sh_lo = odd ? 4u : 0u, sh_hi = 4u - sh_lo;
     const uint32_t* ring = &L.ring[0][0][0];
-    CandData d;
-    bool outside = false;
-    const uint32_t slot0 = pc_slot(rr - 2);
+    uint32_t lo[5], hi[5];
 #pragma unroll
     for (int r = 0; r < 5; ++r) {
-      const int wr = rr - 2 + r;  // strip row of this window row: -2 .. RA + 1
-      const uint32_t slot = slot0 + (uint32_t)r - (slot0 + (uint32_t)r >= PC_RING ? PC_RING : 0u);
-      const uint32_t d0 = ring[slot * 256 + D], d1 = ring[slot * 256 + D + 1];  // (D + 1 == 256 only where its half is not used)
-      d.lo[r] = d0 >> sh_lo;
-      d.hi[r] = (odd ? d1 : d0) >> sh_hi;
-      outside = outside || (act && (wr < -1 || wr > (int)R.RA));
+      const uint32_t so = j2 ? S[r + 2] : (j1 ? S[r + 1] : S[r]);
+      const uint32_t d0 = ring[so + D], d1 = ring[so + D + 1];  // (D + 1 == 256 only where its half is not used)
+      lo[r] = d0 >> sh_lo;
+      hi[r] = (odd ? d1 : d0) >> sh_hi;
     }
-    if (__builtin_amdgcn_ballot_w64(outside)) {  // the rows just outside the strip: not streamed, from global memory
-      const uint8_t* base = p.frames + (size_t)(R.f0 + fr) * p.W * p.H + ((x - 2) & ~3u);
-      const int r_out = rr < 2 ? 0 : 4;  // (row -2 is window row 0 of strip row 0, row RA + 1 window row 4 of strip row RA - 1)
-      if (outside) {
-        const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)(y - 2 + r_out) * p.W);
-        if (r_out == 0) d.lo[0] = v.x, d.hi[0] = v.y;
-        else d.lo[4] = v.x, d.hi[4] = v.y;
+    const uint32_t j = (j1 ? 1u : 0u) + (j2 ? 1u : 0u);
+    if (edge) {  // the rows just outside the strip (-2, RA + 1) are not streamed: from global memory
+      const int rr = k0 + (int)j;  // strip row of the candidate
+      const bool outside = act && (rr < 1 || rr + 2 > (int)R.RA);
+      if (__builtin_amdgcn_ballot_w64(outside)) {
+        const uint32_t fr = (owner * R.magic) >> 16, col = owner - fr * R.Wc;
+        const uint8_t* base = p.frames + (size_t)(R.f0 + fr) * p.W * p.H + ((col * 32 + b - 2) & ~3u);
+        const int r_out = rr < 2 ? 0 : 4;  // (row -2 is window row 0 of strip row 0, row RA + 1 window row 4 of strip row RA - 1)
+        if (outside) {
+          const uint2 v = *reinterpret_cast<const uint2*>(base + (size_t)((int)R.ya + rr - 2 + r_out) * p.W);
+          if (r_out == 0) lo[0] = v.x, hi[0] = v.y;
+          else lo[4] = v.x, hi[4] = v.y;
+        }
       }
     }
-    BsWin Wn;
+    BsWin Wn;  // natives: pixels x-2 .. x+1 of each row as bytes, and pixel x+2
+    {
+      const uint32_t sa = (b - 2u) & 3u;
+#pragma unroll
+      for (int r = 0; r < 5; ++r) {
+        Wn.w[r] = __builtin_amdgcn_alignbyte(hi[r], lo[r], sa) & 0x0f0f0f0fu;
+        Wn.e[r] = (hi[r] >> (8u * sa)) & 15u;
+      }
+    }
     uint32_t vr[7];
-    bs_window(d, x, Wn);
     bs_ranks(Wn, vr);
     const uint32_t p3 = bs_p3(vr);
     // the pixel's median: the native colour of the 4th largest of its 3x3 (kpe.hpp:313-315), as a patch of its nibble
@@ -272,8 +285,7 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
     const uint32_t res = act ? (owner | j << 6 | b << 8 | delta << 13 | 0x80000000u) : 0u;
     if (r0 < 64 * PC_REG_PASSES) {  // uniform
 #pragma unroll
-      for (uint32_t q = 0; q < PC_REG_PASSES; ++q)
-        if (r0 == 64 * q) R.cur[q] = res;
+      for (uint32_t q = 0; q < PC_REG_PASSES; ++q) R.cur[q] = r0 == 64 * q ? res : R.cur[q];  // (selects, not a tree of scalar branches)
     } else {
       if (act) atomicXor(&R.ovf[((R.gen * 3 + j) * 64 + owner) * 4 + (b >> 3)], delta << (8u * (b & 3u) + (b & 4u)));
       R.ovf_cur = 1;
@@ -284,6 +296,8 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
     if (km) {
       if (R.nst + (uint32_t)__builtin_popcountll(km) > PC_STASH) pc_flush(p, R);  // (uniform; the new ones are still in registers)
       if (kp) {
+        const uint32_t fr = (owner * R.magic) >> 16, col = owner - fr * R.Wc;
+        const uint32_t x = col * 32 + b, y = R.ya + (uint32_t)k0 + j;
         uint32_t* st = L.stash[R.nst + mbcnt(km)];
         *reinterpret_cast<uint4*>(st) = make_uint4(Wn.w[0], Wn.w[1], Wn.w[2], Wn.w[3]);
         *reinterpret_cast<uint4*>(st + 4) =
@@ -296,11 +310,17 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
   }
   // ---- rows k0 - 2 .. k0 are final once these patches are in: row k0's from this roll, the two above from the one before
   const uint32_t s0 = pc_slot(k0 - 2), s1 = pc_slot(k0 - 1), s2 = pc_slot(k0);
+  const uint32_t ncur = min((T + 63u) >> 6, PC_REG_PASSES);  // (uniform) register passes of this roll
 #pragma unroll
   for (uint32_t q = 0; q < PC_REG_PASSES; ++q) {
-    const uint32_t ec = R.cur[q], ep = R.prev[q], jp = (ep >> 6) & 3u;
-    pc_patch(L, ep, jp == 1 ? s0 : s1, (ep >> 31) && jp != 0);
-    pc_patch(L, ec, s2, (ec >> 31) && ((ec >> 6) & 3u) == 0);
+    if (q < R.nprev) {
+      const uint32_t ep = R.prev[q], jp = (ep >> 6) & 3u;
+      pc_patch(L, ep, jp == 1 ? s0 : s1, (ep >> 31) && jp != 0);
+    }
+    if (q < ncur) {
+      const uint32_t ec = R.cur[q];
+      pc_patch(L, ec, s2, (ec >> 31) && ((ec >> 6) & 3u) == 0);
+    }
   }
   if (R.ovf_prev | R.ovf_cur) {  // uniform: the patches that did not fit the registers, per owner
     // (this wave's own atomics, performed at its XCD's L2: they only have to have left the wave — an agent-scope
@@ -328,6 +348,7 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
   }
 #pragma unroll
   for (uint32_t q = 0; q < PC_REG_PASSES; ++q) R.prev[q] = R.cur[q];
+  R.nprev = ncur;
   R.ovf_prev = R.ovf_cur;
   R.gen ^= 1u;
 }
@@ -372,14 +393,17 @@ __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
     ld_b = ok_b ? (uint32_t)((size_t)rb * frame_bytes) + cb * 32 + half * 16 : 0u;
     roll.st_a = ok_a ? ld_a : 0x80000000u;  // dropped by the range check
     roll.st_b = ok_b ? ld_b : 0x80000000u;
-    roll.ma0 = ca == 0 && half == 0 ? 0xffff0000u : 0xffffffffu;
-    roll.ma3 = ca == Wc - 1 && half == 1 ? 0x0000ffffu : 0xffffffffu;
-    roll.mb0 = cb == 0 && half == 0 ? 0xffff0000u : 0xffffffffu;
-    roll.mb3 = cb == Wc - 1 && half == 1 ? 0x0000ffffu : 0xffffffffu;
+    roll.ma0 = ca == 0 && half == 0 ? 0x0f0f0000u : 0x0f0f0f0fu;
+    roll.ma3 = ca == Wc - 1 && half == 1 ? 0x00000f0fu : 0x0f0f0f0fu;
+    roll.mb0 = cb == 0 && half == 0 ? 0x0f0f0000u : 0x0f0f0f0fu;
+    roll.mb3 = cb == Wc - 1 && half == 1 ? 0x00000f0fu : 0x0f0f0f0fu;
   }
 
-  const int H = (int)p.H, W = (int)p.W, RA = (int)p.rows_per_strip;  // RA: a multiple of 6
-  const int ya = (int)blockIdx.y * RA;
+  // Strips: long ones first, short ones last (workgroups are dispatched in index order: the short strips fill the
+  // chip while the last long ones finish — a wave alone on a SIMD streams no faster than four do).
+  const bool long_strip = blockIdx.y < p.strips_long;
+  const int H = (int)p.H, W = (int)p.W, RA = (int)(long_strip ? p.rows_per_strip : p.rows_short);  // RA: a multiple of 6
+  const int ya = long_strip ? (int)blockIdx.y * RA : (int)(p.strips_long * p.rows_per_strip + (blockIdx.y - p.strips_long) * p.rows_short);
   // row ya + j of the strip (clamped to the frame: window rows of unprocessed pixels); j > RA is not wanted
   auto load_rows = [&](int j) -> PcRaw {
     PcRaw w;
@@ -395,7 +419,7 @@ __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
   roll.nst = 0;
 #pragma unroll
   for (uint32_t q = 0; q < PC_REG_PASSES; ++q) roll.cur[q] = roll.prev[q] = 0;
-  roll.ovf_cur = roll.ovf_prev = roll.gen = 0;
+  roll.ovf_cur = roll.ovf_prev = roll.gen = roll.nprev = 0;
   // a loaded row (strip row q, -1 .. ) into the ring, two pixels per byte: the row's 2 KB in natural order
   auto ring_put = [&](int q, const PcRaw& w) {
     uint32_t* row = &roll.L->ring[pc_slot(q)][0][0];
@@ -414,10 +438,16 @@ __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
   pc::Upper U;
   u32x4 nb;  // the lane's chunk of the row that becomes B in the next step
   PcRaw pf0, pf1;
+#if RMX_PC_DEPTH == 3
+  PcRaw pf2;
+#endif
   {  // rows -1, 0 and 1 into the ring; what row 0's own test needs from above
     const PcRaw wm = load_rows(-1), w0 = load_rows(0), w1 = load_rows(1);
     pf0 = load_rows(2);
     pf1 = load_rows(3);
+#if RMX_PC_DEPTH == 3
+    pf2 = load_rows(4);
+#endif
     ring_put(-1, wm);
     ring_put(0, w0);
     ring_put(1, w1);
@@ -473,14 +503,23 @@ __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
     RMX_PC_FLAGS(M, B, R)                                                                                  \
     nb = nbn;                                                                                              \
   }
-  static_assert(RMX_PC_DEPTH == 2, "two rows in flight");
+  static_assert(RMX_PC_DEPTH == 2 || RMX_PC_DEPTH == 3, "two or three rows in flight");
   for (int j = 0; j < RA; j += 6) {
+#if RMX_PC_DEPTH == 3
+    RMX_PC_STEP(T0, T1, pf0, 0)
+    RMX_PC_STEP(T1, T0, pf1, 1)
+    RMX_PC_STEP(T0, T1, pf2, 2)
+    RMX_PC_STEP(T1, T0, pf0, 3)
+    RMX_PC_STEP(T0, T1, pf1, 4)
+    RMX_PC_STEP(T1, T0, pf2, 5)
+#else
     RMX_PC_STEP(T0, T1, pf0, 0)
     RMX_PC_STEP(T1, T0, pf1, 1)
     RMX_PC_STEP(T0, T1, pf0, 2)
     RMX_PC_STEP(T1, T0, pf1, 3)
     RMX_PC_STEP(T0, T1, pf0, 4)
     RMX_PC_STEP(T1, T0, pf1, 5)
+#endif
   }
 #undef RMX_PC_STEP
 #undef RMX_PC_FLAGS

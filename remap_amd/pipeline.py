@@ -22,8 +22,42 @@ import numpy as np
 
 from . import lib as L
 
-__all__ = ["shard_range", "Aligner", "gather_boundary_tables", "gather_offsets", "sum_subcanvases",
+__all__ = ["shard_range", "Aligner", "AlignerPipe", "StepResult", "gather_boundary_tables", "gather_offsets", "sum_subcanvases", "sum_bins_mod_2_16",
            "fold_block_summaries", "gather_block_rows", "canvas_boxes"]
+
+
+class StepResult(dict):
+    """What one step of the hot path returns: device tensors of the local block by name.
+
+    A deferred step (`Aligner.align(defer=True)`, `AlignerPipe.align`) is PROVISIONAL until it has been settled:
+    the matcher may have left tickets to `rmx_kpm_resolve` (a region beyond its LDS instances, an instance outside
+    the lane's launch set), and settling rewrites offsets, positions and fragment ids.  Those entries are
+    therefore not readable before `settle()` / `finish()` — reading them after a bare `synchronize()` raises
+    instead of handing out numbers that may still change.  The extraction's outputs (median, desc, kcount) are
+    never rewritten and stay readable."""
+
+    PROVISIONAL = frozenset(("dxdy", "matched", "pos", "frag", "pos_all", "frag_all", "canvases"))  # (`nfrag` is None until then)
+
+    def __init__(self, *a, settled=True, **kw):
+        super().__init__(*a, **kw)
+        self.settled = settled
+
+    def _guard(self, key):
+        if not self.settled and key in self.PROVISIONAL:
+            raise RuntimeError(f"'{key}' of a deferred step is provisional until the step has been settled "
+                               "(AlignerPipe.settle(out) / finish(), Aligner.finish())")
+
+    def __getitem__(self, key):
+        self._guard(key)
+        return dict.__getitem__(self, key)
+
+    def get(self, key, default=None):
+        self._guard(key)
+        return dict.get(self, key, default)
+
+    def raw(self, key):
+        """The entry whatever the state (the pipeline's own use while it settles the step)."""
+        return dict.__getitem__(self, key)
 
 
 def shard_range(n_total: int, rank: int, world: int):
@@ -44,8 +78,13 @@ def _all_gather_flat(flat, world, dist, group):
         out = torch.empty(out_shape, dtype=flat.dtype)
         dist.all_gather_into_tensor(out, host, group=group)
         return out.to(flat.device)
+    # RCCL gathers in place on the device: one contiguous device buffer per rank, same dtype and size everywhere
+    assert flat.is_cuda, "the nccl (RCCL) backend gathers device tensors"
+    assert flat.dtype in (torch.uint8, torch.int32, torch.int16, torch.int64), flat.dtype
+    flat = flat.contiguous()
     out = torch.empty(out_shape, dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(out, flat.contiguous(), group=group)
+    assert out.is_contiguous() and out.numel() == world * flat.numel()
+    dist.all_gather_into_tensor(out, flat, group=group)
     return out
 
 
@@ -143,6 +182,26 @@ def sum_subcanvases(sub, zero, gbox, dist, group=None, device=None):
     return whole if device is None else whole.to(device)
 
 
+def sum_bins_mod_2_16(flat, dist=None, group=None):
+    """In place: the uint16 bins of `flat` (an int16 tensor, every rank's own counts) summed over the ranks modulo
+    2^16 (fgm::dot_type wraps, fgm.hpp:14).  The bins travel as int32 — RCCL has no 16-bit integer type; the sum of
+    at most `world` values below 2^16 cannot overflow — and are narrowed again.  Without a process group (or with
+    one rank) the widening and narrowing still run: the identity, which the tests pin on device tensors."""
+    import torch as t
+
+    assert flat.dtype == t.int16 and flat.is_contiguous()
+    wide = flat.to(t.int32) & 0xffff
+    if dist is not None and dist.is_initialized() and dist.get_world_size(group) > 1:
+        gloo = dist.get_backend(group) == "gloo"
+        if gloo:
+            wide = wide.cpu()
+        else:
+            assert wide.is_cuda and wide.is_contiguous(), "the nccl (RCCL) backend reduces device tensors"
+        dist.all_reduce(wide, op=dist.ReduceOp.SUM, group=group)
+    flat.copy_((wide & 0xffff).to(t.int16))  # int32 -> int16 keeps the low 16 bits
+    return flat
+
+
 def canvas_boxes(pos, starts, W, H):
     """Canvas boxes of fragments that are runs of the stream: pos (n, 2) integer positions, starts = first
     frame of every run.  Returns (w, h, zero_x, zero_y) arrays.  fgm.hpp:190-233 grows the canvas by whole
@@ -238,8 +297,8 @@ class Aligner:
             summ = _all_gather_flat(mine, self.world, self.dist, self.group)
             ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
             nfrag = None if defer else ctx.frc_finish()
-        out = dict(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
-                   lo=lo, hi=hi, nfrag=nfrag, n_total=n_total)
+        out = StepResult(median=median, desc=desc, kcount=kcount, dxdy=dxdy, matched=matched, pos=pos, frag=frag,
+                         lo=lo, hi=hi, nfrag=nfrag, n_total=n_total, settled=not defer)
         if defer:
             assert not blit, "canvases need the positions on the host: not with defer=True"
             assert check, "a deferred step is checked when it is settled"
@@ -286,7 +345,7 @@ class Aligner:
             # thousands of keypoints in one region): tickets computed there, offsets rewritten,
             # positions derived again.  On a sharded stream every rank gets here if one does
             # (the flag travels with the scan summaries), so the collectives below pair up.
-            desc, kcount, dxdy, matched = out["desc"], out["kcount"], out["dxdy"], out["matched"]
+            desc, kcount, dxdy, matched = out.raw("desc"), out.raw("kcount"), out.raw("dxdy"), out.raw("matched")
             ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
             if self.world == 1:
                 pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
@@ -307,6 +366,7 @@ class Aligner:
         self._deferred = None
         out["nfrag"] = self.ctx.frc_finish()
         self._check_step(out, halo)
+        out.settled = True  # offsets, positions and fragment ids are final from here on
         self._last_nfrag = out["nfrag"]
         return self._last_nfrag
 
@@ -408,14 +468,7 @@ class Aligner:
         `world` uint16 values cannot overflow) and are narrowed again — exact modulo 2^16."""
         if self.world == 1:
             return
-        t = self.torch
-        flat = self._layout[0]
-        gloo = self.dist.get_backend(self.group) == "gloo"
-        wide = (flat.to(t.int32) & 0xffff)
-        if gloo:
-            wide = wide.cpu()
-        self.dist.all_reduce(wide, op=self.dist.ReduceOp.SUM, group=self.group)
-        flat.copy_((wide & 0xffff).to(t.int16))  # int32 -> int16 keeps the low 16 bits
+        sum_bins_mod_2_16(self._layout[0], self.dist, self.group)
 
     def fragments(self, frames, out):
         """collector.complete() for a (sharded) stream: the whole canvas of every fragment on every
@@ -441,21 +494,32 @@ class Aligner:
         self.ctx.close()
 
 
+def lane_groups(dist, group, lanes):
+    """One process group per lane over the ranks of `group` (collective: every rank calls it, same arguments)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1 or lanes == 1:
+        return [group] * lanes
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+    backend = dist.get_backend(group)
+    return [dist.new_group(ranks=ranks, backend=backend) for _ in range(lanes)]
+
+
 class AlignerPipe:
     """Blocks of a stream in flight on `lanes` Aligners (each with its own HIP stream and
     workspaces), taken in turn.
 
-    A step of the hot path is one chip-filling kernel (the extraction: kpe_bs_ring / kpe_bs, four fifths of
-    the step's instructions) followed by a chain of small latency-bound ones (table, kpm_build*, kpm_match*,
-    declare, scan) that leave most of the chip idle.  With two lanes the chain of block t runs beside the
-    extraction of block t + 1.  The extraction kernels themselves take turns (rmx_kpe_take_turns: an event
+    A step of the hot path is one chip-filling kernel (the extraction: kpe_pc / kpe_bs_ring / kpe_bs, three
+    quarters of the step's instructions) followed by a chain of small latency-bound ones (table, kpm_build*,
+    kpm_match*, declare, scan) that leave most of the chip idle.  With several lanes (bench.py: three) the chain
+    of block t runs beside the extraction of block t + 1.  The extraction kernels themselves take turns (rmx_kpe_take_turns: an event
     right behind each extraction kernel): two of them side by side only share the chip.
 
     Every block is a step of its own, as with `Aligner.align(defer=True)`: its results are final once it
     has been settled — by `settle(out)`, by its lane's next block, or by `finish()`, which waits for
     all lanes and returns the fragment count of the last block (raises if any block overflowed).
-    With several ranks the lanes share one process group: its collectives run in issue order,
-    which is the same on every rank."""
+    With several ranks every lane gets a process group of its own (the same ranks as `group`, made in the same
+    order on every rank): collectives of ONE group run in issue order on the group's internal stream, so with a
+    shared group lane B's boundary all-gather — which waits for lane B's extraction kernel — would sit in front
+    of lane A's scan-summary all-gather and the lanes would serialise."""
 
     def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2, turns=True):
         import torch
@@ -464,9 +528,10 @@ class AlignerPipe:
         self.device = torch.device("cuda", device)
         self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
         self.lanes = []
-        for s in self.streams:
+        self.groups = lane_groups(dist, group, lanes)
+        for s, g in zip(self.streams, self.groups):
             with torch.cuda.stream(s):  # (a Context adopts the stream that is current when it is made)
-                self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=group))
+                self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=g))
         # turns=False leaves the lanes' extraction kernels free-running: they overlap head to tail and the step gets
         # ~4 % shorter (0.462 against 0.480 ms), but two of them then share the chip for most of their time and a
         # launch's duration says nothing about the kernel any more — bench.py times the headline with turns and
@@ -506,7 +571,7 @@ class AlignerPipe:
                     r = lane._settle()
                 self.torch.cuda.current_stream(self.device).wait_stream(s)
                 return r
-        return out["nfrag"]
+        return out["nfrag"]  # (settled already: by its lane's next block or by finish())
 
     def finish(self):
         t = self.torch

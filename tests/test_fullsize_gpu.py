@@ -183,3 +183,67 @@ def test_submit_drain_blits_equal_synchronous_steps(gpu):
         keep(r)
     assert len(got) == len(blocks)
     pipe.close()
+
+
+def test_deferred_results_are_sealed_until_settled(gpu):
+    """A deferred step's offsets, positions and fragment ids may still be rewritten when the step is settled
+    (tickets left to rmx_kpm_resolve, a matcher instance outside the lane's launch set): reading them after a bare
+    synchronize() raises; after settle() / finish() they are the synchronous step's.  The extraction's outputs are
+    final at once."""
+    import torch
+
+    from remap_amd.pipeline import Aligner, AlignerPipe
+
+    fr, _ = scroller_v1(300, dens=100)
+    d = torch.from_numpy(fr).cuda()
+    al = Aligner(320, 240, kmax=2048)
+    ref = al.align(d)
+    want = {k: ref[k].clone() for k in ("dxdy", "matched", "pos", "frag", "kcount", "median")}
+    out = al.align(d, defer=True)
+    torch.cuda.synchronize()
+    assert out["nfrag"] is None and not out.settled
+    for k in ("dxdy", "matched", "pos", "frag"):
+        with pytest.raises(RuntimeError):
+            out[k]
+        with pytest.raises(RuntimeError):
+            out.get(k)
+    assert torch.equal(out["kcount"], want["kcount"]) and torch.equal(out["median"], want["median"])
+    assert al.finish() == ref["nfrag"] and out.settled
+    for k, v in want.items():
+        assert torch.equal(out[k], v), k
+    al.close()
+    pipe = AlignerPipe(320, 240, kmax=2048, lanes=2)
+    o1, o2 = pipe.align(d), pipe.align(d)
+    torch.cuda.synchronize()
+    for o in (o1, o2):
+        with pytest.raises(RuntimeError):
+            o["dxdy"]
+    assert pipe.settle(o1) == ref["nfrag"] and o1.settled and not o2.settled
+    assert torch.equal(o1["pos"], want["pos"])
+    with pytest.raises(RuntimeError):
+        o2["pos"]
+    o3 = pipe.align(d)  # lane 0 again: nothing of o1 is touched before ... it was settled
+    assert pipe.finish() == ref["nfrag"] and o2.settled and o3.settled
+    assert torch.equal(o2["dxdy"], want["dxdy"]) and torch.equal(o3["frag"], want["frag"])
+    pipe.close()
+
+
+def test_bin_sum_widening_is_exact_on_device(gpu):
+    """sum_bins_mod_2_16 (the canvases' cross-rank sum: int16 bins widened to int32 for the all-reduce, narrowed
+    again) on DEVICE tensors with one rank: the identity for every uint16 value, wrapped ones included — the
+    arithmetic of the nccl branch without a second GPU."""
+    import torch
+
+    from remap_amd.pipeline import sum_bins_mod_2_16
+
+    v = torch.arange(0, 65536, dtype=torch.int32).to(torch.int16).cuda()
+    flat = v.repeat(3).contiguous()
+    before = flat.clone()
+    assert sum_bins_mod_2_16(flat) is flat and torch.equal(flat, before)
+    # two "ranks" by hand: the int32 sum of two uint16 values narrowed = their sum modulo 2^16
+    a = torch.randint(-32768, 32768, (4096,), dtype=torch.int16, device="cuda")
+    b = torch.randint(-32768, 32768, (4096,), dtype=torch.int16, device="cuda")
+    wide = (a.to(torch.int32) & 0xffff) + (b.to(torch.int32) & 0xffff)
+    got = (wide & 0xffff).to(torch.int16)
+    want = ((a.cpu().numpy().view(np.uint16).astype(np.uint32) + b.cpu().numpy().view(np.uint16)) & 0xffff).astype(np.uint16)
+    assert np.array_equal(got.cpu().numpy().view(np.uint16), want)

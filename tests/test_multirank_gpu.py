@@ -230,3 +230,29 @@ def test_two_ranks_resolve_a_huge_region_together(gpu, pipelined, monkeypatch):
         assert np.array_equal(matched, o["matched"][lo:hi]) and np.array_equal(dxdy, o["dxdy"][lo:hi]), rank
         assert np.array_equal(pos, o["pos"][lo:hi]) and np.array_equal(frag, o["frag"][lo:hi]), rank
         assert nf == int(o["frag"].max()) + 1
+
+
+@pytest.mark.timeout(600)
+def test_bench_two_ranks_under_torch_distributed_run(gpu):
+    """bench.py exactly as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N
+    ... bench.py --gpus N`), two ranks on this one card with gloo for the exchanges: the per-rank block from
+    scroller_world, the lanes' process groups, the cross-rank max of the timed region and the exactness check —
+    so that an 8-GPU run is not the first execution of any of those lines.  Launched from a fresh process."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--no-cpu",
+           "--no-workloads", "--headline-only", "--steps", "3", "--warmup", "1", "--spin-up", "0", "--frames", "2000"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]  # rank 0 prints ONE line
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    assert d["offsets_bit_exact_vs_truth"] is True
+    assert d["config"]["frames_total"] == 4000 and "x2" in d["config"]["parallelism"]
+    assert d["value"] > 0 and abs(d["value"] - 4000 / (d["ms_per_step"] * 1e-3)) < 1e-3 * d["value"]
