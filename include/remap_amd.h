@@ -362,6 +362,9 @@ int rmx_debug_kpe_scratch(rmx_ctx* ctx, void* host_dst, size_t bytes);
 /* Diagnostics: the context's 64 device status words (flags, scan carry, launch-set words, and in builds with
  * -DRMX_STATS / -DRMX_KPM_STAMP the matcher's counters and phase times).  Synchronises. */
 int rmx_debug_status(rmx_ctx* ctx, uint32_t* host_words64);
+/* Test hook: OR `bits` into status word `word` (0 = extraction table overflow, 1 = matcher limits, sticky until a
+ * status call reports them), as a kernel that hit the limit would.  Synchronises. */
+int rmx_debug_poke_status(rmx_ctx* ctx, uint32_t word, uint32_t bits);
 
 #ifdef __cplusplus
 }

@@ -36,7 +36,7 @@ SYMBOLS = [
     "rmx_last_kernel_ms", "rmx_kernel_launches", "rmx_malloc", "rmx_free", "rmx_upload", "rmx_download", "rmx_download_2d", "rmx_copy",
     "rmx_memset", "rmx_malloc_host", "rmx_free_host", "rmx_nic_compress_batch", "rmx_nic_bound", "rmx_nic_pack", "rmx_nic_status", "rmx_nic_decompress_batch", "rmx_fdf_filter_batch", "rmx_fdf_status",
     "rmx_debug_umap_order",
-    "rmx_debug_kpe_scratch", "rmx_debug_status", "rmx_kpe_kernel",
+    "rmx_debug_kpe_scratch", "rmx_debug_status", "rmx_debug_poke_status", "rmx_kpe_kernel",
     "rmx_fgm_blit_fresh",
     "rmx_kpm_adaptive", "rmx_kpm_launch_set", "rmx_kpe_take_turns", "rmx_kpe_wait_turn",
 ]
@@ -121,6 +121,7 @@ def load():
     lib.rmx_debug_umap_order.argtypes = [vp, vp, u32, vp]
     lib.rmx_debug_kpe_scratch.argtypes = [vp, vp, C.c_size_t]
     lib.rmx_debug_status.argtypes = [vp, vp]
+    lib.rmx_debug_poke_status.argtypes = [vp, u32, u32]
     lib.rmx_kpe_kernel.argtypes = [vp]
     lib.rmx_kpe_kernel.restype = C.c_char_p
     lib.rmx_kpm_tickets.argtypes = [vp, u32, vp]

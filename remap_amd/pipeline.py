@@ -73,8 +73,8 @@ def _all_gather_flat(flat, world, dist, group):
     import torch
 
     out_shape = (world * flat.shape[0],) + tuple(flat.shape[1:])
-    if dist.get_backend(group) == "gloo" and flat.is_cuda:
-        host = flat.cpu()
+    if dist.get_backend(group) == "gloo":
+        host = flat.cpu() if flat.is_cuda else flat.contiguous()
         out = torch.empty(out_shape, dtype=flat.dtype)
         dist.all_gather_into_tensor(out, host, group=group)
         return out.to(flat.device)
@@ -346,16 +346,31 @@ class Aligner:
             # positions derived again.  On a sharded stream every rank gets here if one does
             # (the flag travels with the scan summaries), so the collectives below pair up.
             desc, kcount, dxdy, matched = out.raw("desc"), out.raw("kcount"), out.raw("dxdy"), out.raw("matched")
-            ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
+            # (a hard limit inside the redone pass raises here on this rank; the other ranks learn of it from the
+            # failure bit of the summaries gathered below, so no rank is left alone in a collective)
+            err = None
+            try:
+                ctx.kpm_resolve(desc, kcount, dxdy, matched, halo=halo)
+            except L.RemapError as e:
+                if self.world == 1:
+                    raise
+                err = e
+                ctx.lib.rmx_debug_poke_status(ctx.h, 1, 4)  # the sticky word the scan summary reads its failure bit from
             if self.world == 1:
                 pos, frag, carry = ctx.frc_scan(dxdy, matched, first_is_start=True)
                 nfrag = carry[1] + 1
+                _, fl2 = ctx.kpm_status()
             else:
                 pos, frag, mine = ctx.frc_scan_block(dxdy, matched, first_is_start=(self.rank == 0))
                 summ = _all_gather_flat(mine, self.world, self.dist, self.group)
                 ctx.frc_apply_blocks(summ.contiguous(), self.rank, self.world, pos, frag)
                 nfrag = ctx.frc_finish()
-                ctx.kpm_status()  # (the flag of the first pass, gathered again)
+                _, fl2 = ctx.kpm_status()  # (128: the flag of the first pass, gathered again)
+            if err is not None:
+                raise err
+            if fl2 & ~128:  # the redone pass is the only one that built the frames its first pass skipped
+                where = "another rank's block" if fl2 & L.RMX_KPM_REMOTE_FAILURE and not fl2 & ~(128 | L.RMX_KPM_REMOTE_FAILURE) else "this block"
+                raise L.RemapError(L.RMX_ERR_CAPACITY, "rmx_kpm_resolve", f"matcher workspace limit in the redone step ({where}), flags={fl2}")
             out.update(pos=pos, frag=frag, nfrag=nfrag)
 
     def _settle(self):

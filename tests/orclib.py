@@ -32,6 +32,8 @@ def ptr(a, t=C.c_void_p):
 
 
 def build_oracle():
+    if os.environ.get("RMX_ORACLE_SO"):  # another build of the restatement (oracle/Makefile: the sanitizer build)
+        return os.environ["RMX_ORACLE_SO"]
     so = os.path.join(ORACLE_DIR, "libremap_oracle.so")
     src = os.path.join(ORACLE_DIR, "remap_oracle.cpp")
     if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):

@@ -11,6 +11,8 @@ from remap_amd import lib as L
 from remap_amd.synth import mt19937_raw, scroller_v1, upscale2
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# extra flags for the host-side checks compiled below (oracle/Makefile `asan-test`: -fsanitize=address,undefined)
+HOSTCHECK_FLAGS = os.environ.get("RMX_HOSTCHECK_CXXFLAGS", "").split()
 
 
 def test_umap_order_emulation_equals_libstdcxx():
@@ -153,7 +155,7 @@ def test_bitplane_3x3_pass_matches_oracle(tmp_path):
     from remap_amd.synth import scroller_v1
 
     so = tmp_path / "libbitslice_check.so"
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", str(so),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", *HOSTCHECK_FLAGS, "-o", str(so),
                            os.path.join(ROOT, "tests", "cpp", "bitslice_check.cpp")])
     lib = ctypes.CDLL(str(so))
     lib.bs_planes_roundtrip.argtypes = [ctypes.c_void_p] * 3
@@ -219,7 +221,7 @@ def test_pairwise_candidate_test_matches_oracle(tmp_path):
     from remap_amd.synth import scroller_v1
 
     so = tmp_path / "libpaircmp_check.so"
-    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", "-o", str(so),
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-shared", "-fPIC", *HOSTCHECK_FLAGS, "-o", str(so),
                            os.path.join(ROOT, "tests", "cpp", "paircmp_check.cpp")])
     lib = ctypes.CDLL(str(so))
     lib.pc_kpe_cand.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_uint32]

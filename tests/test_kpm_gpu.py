@@ -431,3 +431,44 @@ def test_adaptive_launch_set_learns_and_recovers(gpu):
     assert same(out, "dense")
     al2.close()
     al.close()
+
+
+def test_redone_step_that_hits_a_hard_limit_is_not_returned_as_good(gpu):
+    """The adaptive launch set: a step that needed an instance outside the set is redone by rmx_kpm_resolve with
+    every instance — the ONLY pass that builds the frames the first one skipped.  If that pass raises a matcher
+    limit other than "tickets left" (status word 1, sticky) and leaves no ticket for the global-memory instance,
+    resolve used to return RMX_OK from its "nothing left to do" exits and the step's offsets went out as good.
+    The limit is injected (rmx_debug_poke_status) between the first pass and the redo."""
+    import torch
+
+    from remap_amd.pipeline import Aligner
+
+    sparse, _ = scroller_v1(200, dens=200)
+    dense, _ = scroller_v1(200, dens=40, cam_seed=5)
+    d_sparse, d_dense = torch.from_numpy(sparse).cuda(), torch.from_numpy(dense).cuda()
+    ctx = L.Context(320, 240, kmax=4096)
+    ctx.kpm_adaptive(True)
+    med, desc, kc = ctx.kpe(d_sparse)
+    dxdy, matched = ctx.kpm_seq(desc, kc)
+    assert ctx.kpm_status() == (0, 0) and ctx.kpm_launch_set() != 127  # learned: the sparse stream's instances only
+    ctx.kpe(d_dense, med, desc, kc)
+    dxdy, matched = ctx.kpm_seq(desc, kc)
+    rc, fl = ctx.kpm_status()
+    assert rc == L.RMX_ERR_CAPACITY and fl == 128  # "redo me": frames waiting for an instance that was not launched
+    ctx._chk(ctx.lib.rmx_debug_poke_status(ctx.h, 1, 4), "poke")  # ... and the redo "hits" a hard limit
+    with pytest.raises(L.RemapError) as ei:
+        ctx.kpm_resolve(desc, kc, dxdy, matched)
+    assert ei.value.code == L.RMX_ERR_CAPACITY
+    assert ctx.kpm_status() == (0, 0)  # reported once
+    # the same through the Aligner: the error surfaces at the step it belongs to, the Aligner goes on
+    al = Aligner(320, 240, kmax=4096)
+    al.align(d_sparse)
+    out = al.align(d_dense, defer=True)
+    torch.cuda.synchronize()
+    al.ctx.lib.rmx_debug_poke_status(al.ctx.h, 1, 4)
+    with pytest.raises(L.RemapError):
+        al.finish()
+    ok = al.align(d_dense)
+    assert ok["nfrag"] >= 1
+    al.close()
+    ctx.close()
