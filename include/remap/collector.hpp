@@ -12,7 +12,9 @@
 // promises.  Nothing is computed on the host.
 #pragma once
 
+#include <condition_variable>
 #include <exception>
+#include <mutex>
 #include <list>
 #include <optional>
 #include <future>
@@ -228,7 +230,9 @@ public:
   static inline constexpr std::uint32_t max_kmax = 1u << 22;
 
   collector(mrl::dimensions_t d)
-      : dim_{d}, ctx_{remap::context_cache::get(std::uint32_t(d.width_), std::uint32_t(d.height_), 4, 2, 16, kmax)} {}
+      : dim_{d}, ctx_{remap::context_cache::get(std::uint32_t(d.width_), std::uint32_t(d.height_), 4, 2, 16, kmax)} {
+    if (char const* e = std::getenv("REMAP_BLOCK_FRAMES")) block_size_ = std::max<std::uint32_t>(1, std::uint32_t(std::atoi(e)));  // (tuning: tools/time_dropin.py)
+  }
 
   // The callback of frc.hpp:119 borrows the current fragment.  By default a run of frames of one
   // fragment is blitted in one launch BEFORE its callbacks are replayed, so a callback that
@@ -264,112 +268,212 @@ public:
     std::int32_t carry_pos[2] = {0, 0};
     std::uint32_t carry_frag = 0;
     remap::detail::phase_clock clk;
-    // ---- the feed is drained in blocks into one of two host arenas (reused block after block: their pages are
-    // touched once).  With prefetch_feed(true) the NEXT block is produced by a helper thread while this one is
-    // on the device and in its callbacks; otherwise after them, on this thread (the reference's order of calls
-    // per block) ----
-    std::vector<frame_type> block, next_block;
-    unsigned cur = 0;
-    auto fill = [&](std::vector<frame_type>& b, all::memory_pool& pool) {
-      b.clear();
-      pool.reset();
-      while (feed.has_more() && b.size() < block_size_) b.push_back(feed.produce(pixel_alloc_t{pool}));
+    // ---- Blocks in flight.  The feed is drained in blocks into `lanes` slots, each with its own context (a HIP
+    // stream of its own), device buffers and page-locked staging.  A helper thread STAGES the blocks in feed
+    // order — frames gathered into page-locked memory, one copy across PCIe, the extraction kernel, all enqueued
+    // on the slot's stream — while the calling thread FINISHES the block before: matcher (the previous block's last
+    // table is its halo), position scan, results to the host, canvas blit, and the callbacks, once per frame in
+    // frame order (frc.hpp:119).  With three slots the gathering of block t + 2 runs beside the PCIe copy of block
+    // t + 1 and the callbacks of block t.  Nothing else is concurrent: the feeder is called by ONE thread at a time
+    // (the calling thread, blocks ahead of their callbacks; with prefetch_feed(true) the helper), the callbacks
+    // by the calling thread only. ----
+    std::mutex mu;
+    std::condition_variable cv;
+    bool stop = false;
+    enum : int { slot_free = 0, slot_filled = 1, slot_ready = 2, slot_eof = 3 };
+    for (auto& s : slots_) s.state = slot_free, s.error = nullptr, s.block.clear();
+    auto fill = [&](slot_t& s) {
+      s.block.clear();
+      s.pool.reset();
+      while (feed.has_more() && s.block.size() < block_size_) s.block.push_back(feed.produce(pixel_alloc_t{s.pool}));
     };
-    std::future<void> pending;  // (declared after the blocks: joined before they go)
+    const bool profile = std::getenv("REMAP_PROFILE") != nullptr;
+    double t_fill = 0, t_reserve = 0, t_gather = 0, t_enqueue = 0, t_idle = 0;  // (the helper's own clock)
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+    auto stage = [&](slot_t& s, std::uint32_t lane) {  // (helper thread) frames -> HBM, extraction enqueued
+      const std::uint32_t n = std::uint32_t(s.block.size());
+      auto t0 = now();
+      std::uint32_t km;
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        km = kmax_;
+      }
+      s.n = n;
+      reserve_slot(s, lane, n, km);
+      t_reserve += since(t0), t0 = now();
+      std::uint8_t* dst = s.stage.template get<std::uint8_t>();
+      const unsigned gatherers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
+      auto gather = [&, dst](unsigned w) {
+        for (std::uint32_t i = w; i < n; i += gatherers) std::memcpy(dst + i * area, std::as_const(s.block[i].image_).data(), area);  // (const: a view stays a view)
+      };
+      std::vector<std::thread> helpers;
+      for (unsigned w = 1; w < gatherers; ++w) helpers.emplace_back(gather, w);
+      gather(0);
+      for (auto& th : helpers) th.join();
+      t_gather += since(t0), t0 = now();
+      // (a kernel copy, not a DMA: the few hundred kilobytes the block before hands back would queue behind these
+      // 300 MB on the same engine — measured: its downloads took 37 ms per block instead of 0.6)
+      remap::check(rmx_upload_pinned(s.ctx, s.frames.template get<std::uint8_t>(), dst, std::size_t(n) * area), s.ctx, "rmx_upload_pinned");
+      remap::check(rmx_kpe_batch(s.ctx, s.frames.template get<std::uint8_t>(), n, s.median.template get<std::uint8_t>(),
+                                 s.desc.template get<rmx_desc>(), s.kcount.template get<std::uint32_t>()),
+                   s.ctx, "rmx_kpe_batch");
+      t_enqueue += since(t0);
+    };
+    const bool prefetch = prefetch_feed_;
+    std::thread helper([&] {
+      for (std::uint32_t b = 0;; ++b) {
+        slot_t& s = slots_[b % lanes];
+        {
+          auto t0 = now();
+          std::unique_lock<std::mutex> lock(mu);
+          cv.wait(lock, [&] { return stop || s.state == (prefetch ? slot_free : slot_filled) || (!prefetch && s.state == slot_eof); });
+          t_idle += since(t0);
+          if (stop || s.state == slot_eof) break;
+        }
+        int next = slot_ready;
+        try {
+          auto t0 = now();
+          if (prefetch) fill(s);
+          t_fill += since(t0);
+          if (s.block.empty()) next = slot_eof;
+          else stage(s, b % lanes);
+        } catch (...) {
+          s.error = std::current_exception();
+        }
+        {
+          std::lock_guard<std::mutex> lock(mu);
+          s.state = next;
+        }
+        cv.notify_all();
+        if (next == slot_eof || s.error) break;
+      }
+      if (profile)
+        std::fprintf(stderr, "[remap] staging thread: feed.produce %.1f ms, buffers %.1f ms, gather %.1f ms, enqueue (copy + extraction) %.1f ms, waiting for a free slot %.1f ms\n",
+                     t_fill * 1e3, t_reserve * 1e3, t_gather * 1e3, t_enqueue * 1e3, t_idle * 1e3);
+    });
+    struct joiner {  // the helper is stopped and joined on every way out of collect()
+      std::thread& t;
+      std::mutex& mu;
+      std::condition_variable& cv;
+      bool& stop;
+      ~joiner() {
+        {
+          std::lock_guard<std::mutex> lock(mu);
+          stop = true;
+        }
+        cv.notify_all();
+        if (t.joinable()) t.join();
+      }
+    } join_helper{helper, mu, cv, stop};
+    std::uint32_t produced = 0;  // blocks the calling thread has filled (without prefetch_feed)
+    bool feed_done = false;
     clk.mark(nullptr);
-    fill(block, feed_pool_[0]);
-    clk.mark("feed.produce");
-    while (!block.empty()) {
-      clk.mark(nullptr);
-      if (prefetch_feed_) pending = std::async(std::launch::async, [&, nxt = cur ^ 1u] { fill(next_block, feed_pool_[nxt]); });
-      const std::uint32_t n = std::uint32_t(block.size());
+    for (std::uint32_t b = 0;; ++b) {
+      // the feed, on this thread: blocks ahead of their callbacks, never beside them
+      while (!prefetch && !feed_done && produced < b + lanes) {
+        slot_t& f = slots_[produced % lanes];  // (free: the block that held it was finished `lanes` blocks ago)
+        fill(f);
+        feed_done = f.block.empty();
+        {
+          std::lock_guard<std::mutex> lock(mu);
+          f.state = feed_done ? slot_eof : slot_filled;
+        }
+        cv.notify_all();
+        ++produced;
+      }
+      clk.mark("feed.produce");
+      slot_t& s = slots_[b % lanes];
+      {
+        std::unique_lock<std::mutex> lock(mu);
+        cv.wait(lock, [&] { return s.state == slot_ready || s.state == slot_eof; });
+      }
+      if (s.error) std::rethrow_exception(s.error);
+      if (s.state == slot_eof) break;
+      clk.mark("waiting for the staged block (gather, PCIe copy, extraction)");
+      const std::uint32_t n = s.n;
+      std::vector<frame_type>& block = s.block;
       std::uint32_t maxk = 0;
       const std::int32_t carry_pos0[2] = {carry_pos[0], carry_pos[1]};
       const std::uint32_t carry_frag0 = carry_frag;
-      for (;;) {  // one pass, unless a frame has more keypoints than the tables hold
       reserve(n);
-      // frames are gathered in page-locked memory and cross PCIe in one copy
-      stage_.reserve(ctx_, std::size_t(n) * area);
-      {
-        std::uint8_t* stage = stage_.template get<std::uint8_t>();  // (thread_local: this thread's buffer)
-        const unsigned gatherers = std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 8u);
-        auto gather = [&, stage](unsigned w) {
-          for (std::uint32_t i = w; i < n; i += gatherers) std::memcpy(stage + i * area, std::as_const(block[i].image_).data(), area);  // (const: a view stays a view)
-        };
-        std::vector<std::thread> helpers;
-        for (unsigned w = 1; w < gatherers; ++w) helpers.emplace_back(gather, w);
-        gather(0);
-        for (auto& th : helpers) th.join();
-      }
-      remap::check(rmx_upload(ctx_, frames_.get<std::uint8_t>(), stage_.get(), std::size_t(n) * area), ctx_, "rmx_upload");
-      clk.mark("stage + upload");
-      // ---- the hot path, all on the device ----
-      remap::check(rmx_kpe_batch(ctx_, frames_.get<std::uint8_t>(), n, median_.get<std::uint8_t>(),
-                                 desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>()),
-                   ctx_, "rmx_kpe_batch");
-      remap::check(rmx_kpm_seq(ctx_, desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>(), n,
-                               first ? nullptr : halo_.get<rmx_desc>(),
-                               first ? nullptr : reinterpret_cast<std::uint32_t const*>(
-                                                     halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc)),
-                               dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>()),
-                   ctx_, "rmx_kpm_seq");
-      remap::check(rmx_frc_scan(ctx_, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0,
-                                carry_pos, &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
-                   ctx_, "rmx_frc_scan");
-      const int kst = rmx_kpe_status(ctx_, &maxk);
-      if (kst == RMX_ERR_KMAX && maxk <= max_kmax) {  // larger tables, same block again
-        (void)rmx_kpm_status(ctx_, nullptr);          // (its flags belong to the truncated tables)
-        grow_tables(maxk, !first);
-        carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
-        continue;
-      }
-      remap::check(kst, ctx_, "rmx_kpe_status");
-      std::uint32_t kflags = 0;
-      int mst = rmx_kpm_status(ctx_, &kflags);
-      if (mst == RMX_ERR_CAPACITY && kflags == 128u) {
-        // tickets the LDS matcher left to its global-memory instance (thousands of keypoints in
-        // one region): computed there, offsets rewritten, positions derived again
+      for (;;) {  // one pass, unless a frame has more keypoints than the tables hold
+        if (s.kmax != kmax_) {  // the tables have grown since the block was staged: extracted again with the new stride
+          reserve_slot(s, b % lanes, n, kmax_);
+          remap::check(rmx_kpe_batch(s.ctx, s.frames.template get<std::uint8_t>(), n, s.median.template get<std::uint8_t>(),
+                                     s.desc.template get<rmx_desc>(), s.kcount.template get<std::uint32_t>()),
+                       s.ctx, "rmx_kpe_batch");
+        }
+        rmx_ctx* c = s.ctx;
         auto const* hd = first ? nullptr : halo_.get<rmx_desc>();
         auto const* hk = first ? nullptr : reinterpret_cast<std::uint32_t const*>(halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc));
-        remap::check(rmx_kpm_resolve(ctx_, desc_.get<rmx_desc>(), kcount_.get<std::uint32_t>(), n, hd, hk, dxdy_.get<std::int32_t>(),
-                                     matched_.get<std::uint8_t>(), nullptr),
-                     ctx_, "rmx_kpm_resolve");
-        carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
-        remap::check(rmx_frc_scan(ctx_, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0, carry_pos,
-                                  &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
-                     ctx_, "rmx_frc_scan");
-        mst = RMX_OK;
+        remap::check(rmx_kpm_seq(c, s.desc.template get<rmx_desc>(), s.kcount.template get<std::uint32_t>(), n, hd, hk,
+                                 dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>()),
+                     c, "rmx_kpm_seq");
+        remap::check(rmx_frc_scan(c, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0,
+                                  carry_pos, &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
+                     c, "rmx_frc_scan");
+        const int kst = rmx_kpe_status(c, &maxk);
+        if (kst == RMX_ERR_KMAX && maxk <= max_kmax) {  // larger tables, same block again
+          (void)rmx_kpm_status(c, nullptr);             // (its flags belong to the truncated tables)
+          {
+            std::lock_guard<std::mutex> lock(mu);  // (the helper reads the stride when it stages a block)
+            grow_tables(maxk, !first);
+          }
+          carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
+          continue;
+        }
+        remap::check(kst, c, "rmx_kpe_status");
+        std::uint32_t kflags = 0;
+        int mst = rmx_kpm_status(c, &kflags);
+        if (mst == RMX_ERR_CAPACITY && kflags == 128u) {
+          // tickets the LDS matcher left to its global-memory instance (thousands of keypoints in
+          // one region): computed there, offsets rewritten, positions derived again
+          remap::check(rmx_kpm_resolve(c, s.desc.template get<rmx_desc>(), s.kcount.template get<std::uint32_t>(), n, hd, hk,
+                                       dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), nullptr),
+                       c, "rmx_kpm_resolve");
+          carry_pos[0] = carry_pos0[0], carry_pos[1] = carry_pos0[1], carry_frag = carry_frag0;
+          remap::check(rmx_frc_scan(c, dxdy_.get<std::int32_t>(), matched_.get<std::uint8_t>(), n, first ? 1 : 0, carry_pos,
+                                    &carry_frag, pos_.get<std::int32_t>(), frag_.get<std::uint32_t>()),
+                       c, "rmx_frc_scan");
+          mst = RMX_OK;
+        }
+        remap::check(mst, c, "rmx_kpm_status");
+        break;
       }
-      remap::check(mst, ctx_, "rmx_kpm_status");
-      break;
-      }
+      rmx_ctx* const ctx = s.ctx;
       // the last table is the next block's halo
-      remap::check(rmx_copy(ctx_, halo_.get(), desc_.get<rmx_desc>() + std::size_t(n - 1) * kmax_, kmax_ * sizeof(rmx_desc)),
-                   ctx_, "rmx_copy");
-      remap::check(rmx_copy(ctx_, halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc), kcount_.get<std::uint32_t>() + (n - 1), 4),
-                   ctx_, "rmx_copy");
-      clk.mark("device: kpe + kpm + scan");
+      remap::check(rmx_copy(ctx, halo_.get(), s.desc.template get<rmx_desc>() + std::size_t(n - 1) * kmax_, kmax_ * sizeof(rmx_desc)),
+                   ctx, "rmx_copy");
+      remap::check(rmx_copy(ctx, halo_.get<std::uint8_t>() + kmax_ * sizeof(rmx_desc), s.kcount.template get<std::uint32_t>() + (n - 1), 4),
+                   ctx, "rmx_copy");
+      clk.mark("device: kpm + scan");
       // ---- results to the host ----
-      h_pos_.resize(2 * n);
-      h_frag_.resize(n);
-      h_k_.resize(n);
       h_med_.reserve(ctx_, std::size_t(n) * area);
       const std::uint32_t tstride = std::max<std::uint32_t>(1, std::min(maxk, kmax_));  // rows actually used
-      h_tab_.resize(std::size_t(n) * tstride);
-      remap::check(rmx_download(ctx_, h_pos_.data(), pos_.get(), 8 * n), ctx_, "rmx_download");
-      remap::check(rmx_download(ctx_, h_frag_.data(), frag_.get(), 4 * n), ctx_, "rmx_download");
-      remap::check(rmx_download(ctx_, h_k_.data(), kcount_.get(), 4 * n), ctx_, "rmx_download");
-      remap::check(rmx_download_2d(ctx_, h_tab_.data(), tstride * sizeof(rmx_desc), desc_.get(), kmax_ * sizeof(rmx_desc),
-                                   tstride * sizeof(rmx_desc), n),
-                   ctx_, "rmx_download_2d");
+      // (one page-locked block: positions | fragment ids | counts | tables cut to the rows in use; written by the
+      // device itself, one wait)
+      const std::size_t o_frag = 8 * std::size_t(n), o_k = o_frag + 4 * std::size_t(n), o_tab = (o_k + 4 * std::size_t(n) + 15) / 16 * 16;
+      h_res_.reserve(ctx_, o_tab + std::size_t(n) * tstride * sizeof(rmx_desc));
+      std::uint8_t* const res = h_res_.template get<std::uint8_t>();
+      remap::check(rmx_download_pinned(ctx, res, pos_.get(), 8 * std::size_t(n)), ctx, "rmx_download_pinned");
+      remap::check(rmx_download_pinned(ctx, res + o_frag, frag_.get(), 4 * std::size_t(n)), ctx, "rmx_download_pinned");
+      remap::check(rmx_download_pinned(ctx, res + o_k, s.kcount.get(), 4 * std::size_t(n)), ctx, "rmx_download_pinned");
+      remap::check(rmx_download_2d_pinned(ctx, res + o_tab, s.desc.get(), kmax_ * sizeof(rmx_desc), tstride * sizeof(rmx_desc), n),
+                   ctx, "rmx_download_2d_pinned");
+      remap::check(rmx_sync(ctx), ctx, "rmx_sync");
+      const std::int32_t* const h_pos_ = reinterpret_cast<const std::int32_t*>(res);
+      const std::uint32_t* const h_frag_ = reinterpret_cast<const std::uint32_t*>(res + o_frag);
+      const std::uint32_t* const h_k_ = reinterpret_cast<const std::uint32_t*>(res + o_k);
+      const rmx_desc* const h_tab = reinterpret_cast<const rmx_desc*>(res + o_tab);
       clk.mark("downloads");
       // ---- frame blobs: nic::compression is run on the device for the whole block (two
       // launches: images, medians); any other compressor is called per frame below ----
       constexpr bool device_codec = std::is_same_v<std::decay_t<Comp>, nic::compression>;
       std::vector<icd::compressed_t> pk_image, pk_median;
       if constexpr (device_codec) {
-        pk_image = nic::detail::compress_device(ctx_, frames_.get<std::uint8_t>(), n, std::uint32_t(area));
-        pk_median = nic::detail::compress_device(ctx_, median_.get<std::uint8_t>(), n, std::uint32_t(area));
+        pk_image = nic::detail::compress_device(ctx, s.frames.template get<std::uint8_t>(), n, std::uint32_t(area));
+        pk_median = nic::detail::compress_device(ctx, s.median.template get<std::uint8_t>(), n, std::uint32_t(area));
       }
       clk.mark("codec");
       // ---- the per-frame host objects the callbacks borrow (median image, keypoint grid).  Both are made on
@@ -383,11 +487,11 @@ public:
       // (the block's medians cross PCIe in one copy, when the first of them is read: a host-side compressor does
       // that with frame 0, main.cpp's callback with nic::compression never does)
       mrl::cell_loader med_loader{[&] {
-        remap::check(rmx_download(ctx_, h_med_.get(), median_.get(), std::size_t(n) * area), ctx_, "rmx_download");
+        remap::check(rmx_download(ctx, h_med_.get(), s.median.get(), std::size_t(n) * area), ctx, "rmx_download");
       }};
       {
         const auto* med_src = reinterpret_cast<cpl::nat_cc const*>(h_med_.template get<std::uint8_t>());
-        const auto* tab_src = h_tab_.data();
+        const auto* tab_src = h_tab;
         for (std::uint32_t t = 0; t < n; ++t) {
           medians[t].emplace(image_type::view(dim_, med_src + std::size_t(t) * area, pixel_alloc_t{arena}, &med_loader));
           if (first && t == 0) continue;  // process_init has no callback (frc.hpp:83-95)
@@ -402,21 +506,21 @@ public:
         while (j < n && h_frag_[j] == h_frag_[i]) ++j;
         if (fresh || fragments_.empty() || h_frag_[i] != current_id_) add_fragment(h_frag_[i]);
         fresh = false;
-        auto blit_run = [&](std::uint32_t a, std::uint32_t b) {
+        auto blit_run = [&](std::uint32_t a, std::uint32_t e) {
           // grow the canvas once for the whole run, then one batched blit
-          for (std::uint32_t t = a; t < b; ++t) current_->ensure({h_pos_[2 * t], h_pos_[2 * t + 1]}, dim_);
-          remap::check(rmx_fgm_blit_batch(ctx_, frames_.get<std::uint8_t>() + a * area, pos_.get<std::int32_t>() + 2 * a,
-                                          nullptr, 0, b - a, current_->device_canvas(),
+          current_->ensure_run(h_pos_ + 2 * a, e - a, dim_);
+          remap::check(rmx_fgm_blit_batch(ctx, s.frames.template get<std::uint8_t>() + a * area, pos_.get<std::int32_t>() + 2 * a,
+                                          nullptr, 0, e - a, current_->device_canvas(),
                                           std::uint32_t(current_->dim_.width_), std::uint32_t(current_->dim_.height_),
                                           current_->zero_.x_, current_->zero_.y_),
-                       ctx_, "rmx_fgm_blit_batch");
+                       ctx, "rmx_fgm_blit_batch");
         };
         if (!exact_callbacks_) blit_run(i, j);
         // ---- replay: bookkeeping + callback per frame, in order (frc.hpp:117-119) ----
         for (std::uint32_t t = i; t < j; ++t) {
           if (exact_callbacks_) {  // the callback sees the canvas exactly after frame t
             blit_run(t, t + 1);
-            remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
+            remap::check(rmx_sync(ctx), ctx, "rmx_sync");
           }
           image_type const& median = *medians[t];
           fgm::point_t p{h_pos_[2 * t], h_pos_[2 * t + 1]};
@@ -431,14 +535,14 @@ public:
         }
         i = j;
       }
-      remap::check(rmx_sync(ctx_), ctx_, "rmx_sync");
+      remap::check(rmx_sync(ctx), ctx, "rmx_sync");
       clk.mark("blit + replay (callbacks)");
       first = false;
-      if (prefetch_feed_) pending.get();
-      else fill(next_block, feed_pool_[cur ^ 1u]);
-      clk.mark(prefetch_feed_ ? "feed.produce (what the helper thread had left)" : "feed.produce");
-      std::swap(block, next_block);
-      cur ^= 1u;
+      {
+        std::lock_guard<std::mutex> lock(mu);
+        s.state = slot_free;  // its buffers and host frames may be reused
+      }
+      cv.notify_all();
     }
   }
 
@@ -474,13 +578,35 @@ private:
     ctx_ = c;
     kmax_ = k;
   }
-  void reserve(std::uint32_t n) {
+  // one block in flight: its own context (stream), device buffers, page-locked staging and host frames
+  static inline constexpr std::uint32_t lanes = 3;
+  struct slot_t {
+    rmx_ctx* ctx{nullptr};   // the lane's context for the current stride (a HIP stream of its own)
+    rmx_ctx* home{nullptr};  // the context the slot's buffers were allocated with
+    std::uint32_t kmax{0};  // stride the block's tables were extracted with
+    std::uint32_t n{0};
+    remap::device_buffer frames, median, desc, kcount;
+    remap::pinned_buffer stage;
+    std::vector<frame_type> block;
+    all::memory_pool pool;  // feed.produce allocates the block's frames from it
+    int state{0};
+    std::exception_ptr error;
+  };
+  void reserve_slot(slot_t& s, std::uint32_t lane, std::uint32_t n, std::uint32_t kmax) {
     const std::size_t area = dim_.area();
+    s.ctx = remap::context_cache::get_lane(std::uint32_t(dim_.width_), std::uint32_t(dim_.height_), 4, 2, 16, kmax, lane);
+    s.kmax = kmax;
+    // (allocations belong to the lane's first context whatever the stride grows to: a buffer follows the context it
+    // is reserved with, and the frames already uploaded must survive a change of stride)
+    s.home = s.home ? s.home : s.ctx;
+    s.frames.reserve(s.home, n * area);
+    s.median.reserve(s.home, n * area);
+    s.desc.reserve(s.home, std::size_t(n) * kmax * sizeof(rmx_desc));
+    s.kcount.reserve(s.home, 4 * std::size_t(n));
+    s.stage.reserve(s.home, n * area);
+  }
+  void reserve(std::uint32_t n) {
     const std::uint32_t kmax = kmax_;
-    frames_.reserve(ctx_, n * area);
-    median_.reserve(ctx_, n * area);
-    desc_.reserve(ctx_, std::size_t(n) * kmax * sizeof(rmx_desc));
-    kcount_.reserve(ctx_, 4 * std::size_t(n));
     dxdy_.reserve(ctx_, 8 * std::size_t(n));
     matched_.reserve(ctx_, n);
     pos_.reserve(ctx_, 8 * std::size_t(n));
@@ -494,14 +620,11 @@ private:
   bool exact_callbacks_{false};
   bool prefetch_feed_{false};
   std::uint32_t block_size_{block_frames};
-  all::memory_pool feed_pool_[2];  // the frames of the block in flight and of the next one (feed.produce allocates from them)
-  remap::device_buffer frames_, median_, desc_, kcount_, dxdy_, matched_, pos_, frag_, halo_;
-  std::vector<std::int32_t> h_pos_;
-  std::vector<std::uint32_t> h_frag_, h_k_;
-  // page-locked staging (medians coming back, frames going in); shared by the collectors of
-  // a thread: allocating 300 MB of pinned memory costs tens of milliseconds
-  static inline thread_local remap::pinned_buffer h_med_, stage_;
-  std::vector<rmx_desc> h_tab_;
+  slot_t slots_[lanes];
+  remap::device_buffer dxdy_, matched_, pos_, frag_, halo_;  // (the calling thread's: matcher and scan outputs, the halo table)
+  // page-locked block the medians come back into; shared by the collectors of a thread: allocating 300 MB of
+  // pinned memory costs tens of milliseconds
+  static inline thread_local remap::pinned_buffer h_med_, h_res_;  // (h_res_: a block's positions, fragment ids, counts and tables)
   std::list<fgm::fragment> fragments_;
   fgm::fragment* current_{nullptr};
   std::uint32_t current_id_{0};

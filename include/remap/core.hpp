@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <tuple>
 #include <utility>
 #include <vector>
@@ -151,15 +152,13 @@ using region_t = cdt::region<size_type>;
 // copy) turns the view into an owning matrix first.
 // What fills the memory a group of views borrows, run once, by whichever view is read first (frc::collector:
 // the medians of a block come back from the device in ONE copy, and only if a callback looks at one).
+// (read through const accessors, possibly from several threads of a callback — the reference matches regions
+// under std::execution::par: the first reader fills, the others wait for it)
 struct cell_loader {
   std::function<void()> fill;
-  bool done{false};
-  void ensure() {
-    if (!done) {
-      fill();
-      done = true;
-    }
-  }
+  std::once_flag once;
+  explicit cell_loader(std::function<void()> f) : fill{std::move(f)} {}
+  void ensure() { std::call_once(once, fill); }
 };
 
 template <typename T, typename Alloc = std::allocator<T>>

@@ -10,9 +10,11 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
 #include <map>
 #include <memory>
 #include <mutex>
+#include <vector>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -49,12 +51,83 @@ public:
     self.ctx_.emplace(key, c);
     return c;
   }
+  // ... with a stream of its own (RMX_STREAM_OWN), one per `lane`: contexts whose work overlaps (the blocks a
+  // collector keeps in flight: staging and extraction of the next block beside the callbacks of this one)
+  static rmx_ctx* get_lane(std::uint32_t w, std::uint32_t h, std::uint32_t gw, std::uint32_t gh, std::uint32_t ov,
+                           std::uint32_t kmax, std::uint32_t lane) {
+    static context_cache self;
+    std::lock_guard<std::mutex> lock(self.m_);
+    auto key = std::make_tuple(w, h, gw, gh, ov, kmax, lane);
+    auto it = self.lanes_.find(key);
+    if (it != self.lanes_.end()) return it->second;
+    rmx_ctx* c = nullptr;
+    check(rmx_ctx_create(0, w, h, gw, gh, ov, kmax, RMX_STREAM_OWN, &c), nullptr, "rmx_ctx_create");
+    self.lanes_.emplace(key, c);
+    return c;
+  }
 
 private:
   std::mutex m_;
   std::map<std::tuple<std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t>,
            rmx_ctx*>
       ctx_;
+  std::map<std::tuple<std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t, std::uint32_t>,
+           rmx_ctx*>
+      lanes_;
+};
+
+// Freed device blocks are kept and handed out again.  hipFree waits for the whole device — every stream, also the
+// staging and extraction of the blocks a collector has in flight — and a fragment's canvas is reallocated every
+// time it grows: in steady state no allocation reaches the driver any more.  Sizes are rounded up to 2^k or
+// 1.5 * 2^k, so a canvas that grows by a few per cent per block alternates between two blocks of one class.
+// The blocks go back to the driver with trim() or at process exit.
+class device_pool {
+public:
+  static std::size_t size_class(std::size_t bytes) {
+    std::size_t c = 256;
+    while (c < bytes) {
+      if (c + c / 2 >= bytes && c >= 512) return c + c / 2;
+      c <<= 1;
+    }
+    return c;
+  }
+  static void* acquire(rmx_ctx* c, std::size_t bytes, std::size_t& cap) {
+    cap = size_class(bytes);
+    {
+      auto& self = instance();
+      std::lock_guard<std::mutex> lock(self.m_);
+      auto it = self.free_.find(cap);
+      if (it != self.free_.end() && !it->second.empty()) {
+        void* p = it->second.back();
+        it->second.pop_back();
+        return p;
+      }
+    }
+    void* p = nullptr;
+    check(rmx_malloc(c, cap, &p), c, "rmx_malloc");
+    return p;
+  }
+  // (the caller has waited for the work that used the block: the destructors below wait for the owner's stream)
+  static void release(void* p, std::size_t cap) {
+    auto& self = instance();
+    std::lock_guard<std::mutex> lock(self.m_);
+    self.free_[cap].push_back(p);
+  }
+  static void trim(rmx_ctx* c) {
+    auto& self = instance();
+    std::lock_guard<std::mutex> lock(self.m_);
+    for (auto& [cap, v] : self.free_)
+      for (void* p : v) rmx_free(c, p);
+    self.free_.clear();
+  }
+
+private:
+  static device_pool& instance() {
+    static device_pool self;
+    return self;
+  }
+  std::mutex m_;
+  std::map<std::size_t, std::vector<void*>> free_;
 };
 
 // Device allocation tied to a context.
@@ -62,7 +135,7 @@ class device_buffer {
 public:
   device_buffer() = default;
   device_buffer(rmx_ctx* c, std::size_t bytes) : ctx_{c}, bytes_{bytes} {
-    if (bytes) check(rmx_malloc(c, bytes, &p_), c, "rmx_malloc");
+    if (bytes) p_ = device_pool::acquire(c, bytes, cap_);
   }
   device_buffer(device_buffer&& o) noexcept { swap(o); }
   device_buffer& operator=(device_buffer&& o) noexcept {
@@ -73,16 +146,21 @@ public:
   device_buffer(device_buffer const&) = delete;
   device_buffer& operator=(device_buffer const&) = delete;
   ~device_buffer() {
-    if (p_) rmx_free(ctx_, p_);
+    if (p_) {
+      (void)rmx_sync(ctx_);  // what the owner's stream still had to do with it
+      device_pool::release(p_, cap_);
+    }
   }
   void swap(device_buffer& o) noexcept {
     std::swap(ctx_, o.ctx_);
     std::swap(p_, o.p_);
     std::swap(bytes_, o.bytes_);
+    std::swap(cap_, o.cap_);
   }
   // grow-only
   void reserve(rmx_ctx* c, std::size_t bytes) {
-    if (bytes > bytes_ || c != ctx_) *this = device_buffer{c, bytes};
+    if (bytes > cap_ || c != ctx_) *this = device_buffer{c, bytes};
+    else bytes_ = std::max(bytes_, bytes);
   }
   template <typename T = void>
   T* get() const noexcept { return static_cast<T*>(p_); }
@@ -92,7 +170,7 @@ public:
 private:
   rmx_ctx* ctx_{nullptr};
   void* p_{nullptr};
-  std::size_t bytes_{0};
+  std::size_t bytes_{0}, cap_{0};
 };
 
 namespace detail {
@@ -118,31 +196,52 @@ private:
 };
 }  // namespace detail
 
-// Page-locked host staging tied to a context (grow-only).
+// Page-locked host staging tied to a context (grow-only).  Freed blocks are kept for the next buffer of their size
+// class (device_pool's classes): page-locking 300 MB costs ~70 ms, and a collector stages three blocks at a time.
 class pinned_buffer {
 public:
   pinned_buffer() = default;
   pinned_buffer(pinned_buffer const&) = delete;
   pinned_buffer& operator=(pinned_buffer const&) = delete;
-  ~pinned_buffer() {
-    if (p_) rmx_free_host(ctx_, p_);
-  }
+  ~pinned_buffer() { drop(); }
   void reserve(rmx_ctx* c, std::size_t bytes) {
-    if (bytes <= bytes_ && c == ctx_) return;
-    if (p_) rmx_free_host(ctx_, p_);
-    p_ = nullptr;
-    bytes_ = 0;
+    if (bytes <= cap_) return;
+    drop();
     ctx_ = c;
-    check(rmx_malloc_host(c, bytes, &p_), c, "rmx_malloc_host");
-    bytes_ = bytes;
+    cap_ = device_pool::size_class(bytes);
+    {
+      std::lock_guard<std::mutex> lock(mutex());
+      auto it = cache().find(cap_);
+      if (it != cache().end() && !it->second.empty()) {
+        p_ = it->second.back();
+        it->second.pop_back();
+        return;
+      }
+    }
+    check(rmx_malloc_host(c, cap_, &p_), c, "rmx_malloc_host");
   }
   template <typename T = void>
   T* get() const noexcept { return static_cast<T*>(p_); }
 
 private:
+  void drop() {
+    if (!p_) return;
+    std::lock_guard<std::mutex> lock(mutex());
+    cache()[cap_].push_back(p_);
+    p_ = nullptr;
+    cap_ = 0;
+  }
+  static std::mutex& mutex() {
+    static std::mutex m;
+    return m;
+  }
+  static std::map<std::size_t, std::vector<void*>>& cache() {
+    static std::map<std::size_t, std::vector<void*>> c;
+    return c;
+  }
   rmx_ctx* ctx_{nullptr};
   void* p_{nullptr};
-  std::size_t bytes_{0};
+  std::size_t cap_{0};
 };
 
 }  // namespace remap

@@ -19,6 +19,7 @@
 #include <fstream>
 #include <string>
 #include <utility>
+#include <stdexcept>
 #include <vector>
 
 #include "fragment.hpp"
@@ -69,6 +70,8 @@ public:
     good_ = static_cast<bool>(in);
   }
   [[nodiscard]] bool ok() const noexcept { return good_; }
+  [[nodiscard]] std::size_t remaining() const noexcept { return good_ ? bytes_.size() - at_ : 0; }
+  void fail() noexcept { good_ = false; }
   template <typename T>
   [[nodiscard]] T take() {
     T v{};
@@ -103,9 +106,16 @@ private:
 
 [[nodiscard]] inline bool parse_fragment(cursor& c, std::vector<fgm::fragment>& out) {
   auto const dim = c.take<mrl::dimensions_t>();
-  if (!c.ok() || dim.area() == 0) return false;
-  fgm::fragment::matrix_type dots{dim};
-  c.take_into(dots.data(), dim.area() * sizeof(fgm::dot_type));
+  if (!c.ok()) return false;
+  // the canvas is what the header says only if the file holds that many dots: checked before anything is
+  // allocated (a truncated or foreign file must end the parse, not ask for terabytes), without overflow
+  auto const per_row = c.remaining() / sizeof(fgm::dot_type);
+  if (dim.width_ != 0 && dim.height_ > per_row / dim.width_) {
+    c.fail();
+    return false;
+  }
+  fgm::fragment::matrix_type dots{dim};  // (a fragment without a canvas is a valid file: the reference reads it too)
+  c.take_into(dots.data(), dots.size() * sizeof(fgm::dot_type));
   auto const zero = c.take<fgm::point_t>();
   auto const count = c.take<std::uint64_t>();
   std::vector<fgm::frame> frames;
@@ -124,7 +134,9 @@ private:
 }  // namespace details
 
 // Fragments of `dir` in the order of their integer file names (the index write() gave them); entries
-// whose name is not a number are skipped, a file that does not parse ends the list there.
+// whose name is not a number are skipped.  A file that does not parse (truncated, not a fragment file) is an
+// error that names the file — the reference streams whatever bytes it finds; a shortened list handed back
+// silently would lose fragments without a trace.
 [[nodiscard]] inline std::vector<fgm::fragment> read(std::filesystem::path dir) {
   std::vector<std::pair<long, std::filesystem::path>> numbered;
   for (auto const& entry : std::filesystem::directory_iterator(dir)) {
@@ -138,7 +150,8 @@ private:
   fragments.reserve(numbered.size());
   for (auto const& [index, file] : numbered) {
     details::cursor c{file};
-    if (!details::parse_fragment(c, fragments)) break;
+    if (!details::parse_fragment(c, fragments))
+      throw std::runtime_error("ful::read: " + file.string() + ": truncated or not a fragment file");
   }
   return fragments;
 }

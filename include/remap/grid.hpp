@@ -5,7 +5,9 @@
 #pragma once
 
 #include <array>
+#include <atomic>
 #include <cstddef>
+#include <mutex>
 #include <numeric>
 #include <span>
 #include <unordered_map>
@@ -102,9 +104,10 @@ public:
   void add(code const& key, mrl::point_t p, std::index_sequence<I...>) {
     (cells_[I].add(key, p), ...);
   }
-  regions_t regions() const noexcept { return regions_t{materialised().cells_}; }
-  region_type& operator[](std::size_t i) noexcept { return materialised_mut().cells_[i]; }
-  region_type const& operator[](std::size_t i) const noexcept { return materialised().cells_[i]; }
+  // (not noexcept: the first look at a deferred grid builds its maps)
+  regions_t regions() const { return regions_t{materialised().cells_}; }
+  region_type& operator[](std::size_t i) { return materialised_mut().cells_[i]; }
+  region_type const& operator[](std::size_t i) const { return materialised().cells_[i]; }
   bool deferred() const noexcept { return fill_ != nullptr; }
 
 private:
@@ -118,12 +121,21 @@ private:
     fill_ = src.fill_, source_ = src.source_, count_ = src.count_;
     src.fill_ = nullptr;
   }
+  // The deferred state is a cache of what the grid already "holds", filled through const access — possibly by
+  // several threads of one callback at once (the reference's callers match regions under std::execution::par):
+  // one of them fills under a lock, the others wait; a grid that is materialised costs one relaxed-ish load.
+  static std::mutex& fill_mutex() {
+    static std::mutex m;
+    return m;
+  }
   grid& materialised_mut() const {
-    grid& self = const_cast<grid&>(*this);  // (the deferred state is a cache of what the grid already "holds")
-    if (fill_) {
-      fill_fn f = fill_;
-      self.fill_ = nullptr;
-      f(self, source_, count_);
+    grid& self = const_cast<grid&>(*this);
+    if (std::atomic_ref<fill_fn>(self.fill_).load(std::memory_order_acquire)) {
+      std::lock_guard<std::mutex> lock(fill_mutex());
+      if (fill_fn f = self.fill_) {
+        f(self, source_, count_);
+        std::atomic_ref<fill_fn>(self.fill_).store(nullptr, std::memory_order_release);
+      }
     }
     return self;
   }

@@ -69,7 +69,9 @@ typedef struct rmx_ctx rmx_ctx;
  * frc::collector{dims} (frc.hpp:51-53): fixes frame width/height, the region grid
  * (4x2 overlap 16 for frc.hpp:22-26, 1x1 overlap 0 for fgs.hpp:17,85) and the stride
  * (kmax rows, 1 .. 4 194 304) of per-frame descriptor tables.  `stream` is a hipStream_t passed as
- * void* (NULL = the device's default stream). */
+ * void* (NULL = the device's default stream; RMX_STREAM_OWN = a non-blocking stream the library creates for
+ * this context and destroys with it — for callers that keep several blocks in flight without linking HIP). */
+#define RMX_STREAM_OWN ((void*)(intptr_t)-1)
 int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
                    uint32_t grid_h, uint32_t overlap, uint32_t kmax, void* stream,
                    rmx_ctx** out);
@@ -103,6 +105,15 @@ int rmx_free_host(rmx_ctx* ctx, void* ptr);
 int rmx_upload(rmx_ctx* ctx, void* dst_device, const void* src_host, size_t bytes);
 int rmx_download(rmx_ctx* ctx, void* dst_host, const void* src_device, size_t bytes);
 int rmx_copy(rmx_ctx* ctx, void* dst_device, const void* src_device, size_t bytes);
+/* The same transfers done by a few workgroups of the context's stream instead of a DMA engine, for PAGE-LOCKED
+ * host memory (rmx_malloc_host), which the device addresses directly.  All three are asynchronous (rmx_sync
+ * waits).  For callers with blocks in flight on several contexts: DMA copies of different streams share engine
+ * queues, and the few hundred kilobytes a block hands back wait behind the 300 MB the next one brings in —
+ * kernel copies of different streams simply run side by side.  rmx_download_2d_pinned packs `rows` rows of
+ * `width` bytes (spitch apart on the device; all even) back to back into dst. */
+int rmx_upload_pinned(rmx_ctx* ctx, void* dst_device, const void* src_pinned_host, size_t bytes);
+int rmx_download_pinned(rmx_ctx* ctx, void* dst_pinned_host, const void* src_device, size_t bytes);
+int rmx_download_2d_pinned(rmx_ctx* ctx, void* dst_pinned_host, const void* src_device, size_t src_pitch, size_t width, size_t rows);
 /* rows x width bytes from a pitched device array into a pitched host array; synchronises. */
 int rmx_download_2d(rmx_ctx* ctx, void* dst_host, size_t dst_pitch, const void* src_device, size_t src_pitch,
                     size_t width, size_t rows);

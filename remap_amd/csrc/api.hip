@@ -30,6 +30,7 @@ using namespace rmx;
 struct rmx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = false;  // created by rmx_ctx_create (RMX_STREAM_OWN), destroyed with the context
   uint32_t W = 0, H = 0, gw = 0, gh = 0, overlap = 0, kmax = 0;
   Bands bands{};
   // workspace (device)
@@ -235,6 +236,26 @@ __global__ __launch_bounds__(256) void copy_stream(const uint4* __restrict__ src
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) dst[i] = src[i];
 }
+// A copy across PCIe done by a few workgroups instead of a DMA engine (one side is page-locked host memory, which
+// the device addresses directly): a grid-stride walk, 16 bytes per lane where both sides allow it.  The grid is
+// small on purpose — the waves mostly wait for the link, and the chip belongs to the kernels of the other blocks.
+__global__ __launch_bounds__(256) void copy_link(const uint8_t* __restrict__ src, uint8_t* __restrict__ dst, size_t bytes) {
+  const size_t tid = (size_t)blockIdx.x * 256 + threadIdx.x, nt = (size_t)gridDim.x * 256;
+  if (((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15u) == 0) {
+    const size_t n16 = bytes / 16;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    size_t i = tid;
+    for (; i + 3 * nt < n16; i += 4 * nt) {  // four loads in flight per lane
+      const uint4 a = s4[i], b = s4[i + nt], c = s4[i + 2 * nt], d = s4[i + 3 * nt];
+      d4[i] = a, d4[i + nt] = b, d4[i + 2 * nt] = c, d4[i + 3 * nt] = d;
+    }
+    for (; i < n16; i += nt) d4[i] = s4[i];
+    for (size_t j = n16 * 16 + tid; j < bytes; j += nt) dst[j] = src[j];
+  } else {
+    for (size_t j = tid; j < bytes; j += nt) dst[j] = src[j];
+  }
+}
 
 struct Timer {
   rmx_ctx* c;
@@ -298,7 +319,15 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   rmx_ctx* ctx = new (std::nothrow) rmx_ctx();
   if (!ctx) return RMX_ERR_DEVICE;
   ctx->device = device;
-  ctx->stream = (hipStream_t)stream;
+  if (stream == RMX_STREAM_OWN) {  // a non-blocking stream of the context's own (blocks in flight: include/remap/collector.hpp)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+      delete ctx;
+      return RMX_ERR_DEVICE;
+    }
+    ctx->own_stream = true;
+  } else {
+    ctx->stream = (hipStream_t)stream;
+  }
   ctx->W = width;
   ctx->H = height;
   ctx->gw = grid_w;
@@ -325,6 +354,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
       hipMemset(ctx->status, 0, 64 * sizeof(uint32_t)) != hipSuccess ||
       hipHostMalloc(reinterpret_cast<void**>(&ctx->host_words), 16 * sizeof(uint32_t), hipHostMallocDefault) != hipSuccess) {
     if (ctx->status) (void)hipFree(ctx->status);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return RMX_ERR_DEVICE;
   }
@@ -355,6 +385,7 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
   if (ctx->aux) (void)hipStreamDestroy(ctx->aux);
   if (ctx->blit_ws) (void)hipFree(ctx->blit_ws);
   kpm_workspace_free(ctx->kpm);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   for (auto* t : {&ctx->ms_kpe, &ctx->ms_finish, &ctx->ms_table, &ctx->ms_kpm_build, &ctx->ms_kpm_match, &ctx->ms_blit, &ctx->ms_nic, &ctx->ms_fdf}) free_track(*t);
   delete ctx;
   return RMX_OK;
@@ -521,6 +552,34 @@ int rmx_download_2d(rmx_ctx* ctx, void* dst, size_t dpitch, const void* src, siz
   RMX_HIP(hipStreamSynchronize(ctx->stream));
   return RMX_OK;
 }
+int rmx_upload_pinned(rmx_ctx* ctx, void* dst, const void* src_pinned, size_t bytes) {
+  if (!ctx || !dst || !src_pinned) return RMX_ERR_ARG;
+  if (bytes == 0) return RMX_OK;
+  RMX_HIP(hipSetDevice(ctx->device));
+  const uint32_t blocks = (uint32_t)std::min<size_t>(256, (bytes / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(copy_link, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const uint8_t*>(src_pinned), static_cast<uint8_t*>(dst), bytes);
+  RMX_HIP(hipGetLastError());
+  return RMX_OK;
+}
+int rmx_download_pinned(rmx_ctx* ctx, void* dst_pinned, const void* src, size_t bytes) {
+  if (!ctx || !dst_pinned || !src) return RMX_ERR_ARG;
+  if (bytes == 0) return RMX_OK;
+  RMX_HIP(hipSetDevice(ctx->device));
+  const uint32_t blocks = (uint32_t)std::min<size_t>(64, (bytes / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(copy_link, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const uint8_t*>(src), static_cast<uint8_t*>(dst_pinned), bytes);
+  RMX_HIP(hipGetLastError());
+  return RMX_OK;
+}
+int rmx_download_2d_pinned(rmx_ctx* ctx, void* dst_pinned, const void* src, size_t spitch, size_t width, size_t rows) {
+  if (!ctx || !dst_pinned || !src || width > spitch || ((reinterpret_cast<uintptr_t>(src) | spitch | width) & 1u)) return RMX_ERR_ARG;
+  if (width == 0 || rows == 0) return RMX_OK;
+  RMX_HIP(hipSetDevice(ctx->device));
+  const size_t total2 = width * rows / 2;
+  hipLaunchKernelGGL(pack_rows, dim3((uint32_t)((total2 + 255) / 256)), dim3(256), 0, ctx->stream, static_cast<const uint16_t*>(src),
+                     static_cast<uint16_t*>(dst_pinned), spitch / 2, (uint32_t)(width / 2), total2);
+  RMX_HIP(hipGetLastError());
+  return RMX_OK;
+}
 int rmx_copy(rmx_ctx* ctx, void* dst, const void* src, size_t bytes) {
   if (!ctx || !dst || !src) return RMX_ERR_ARG;
   RMX_HIP(hipSetDevice(ctx->device));
@@ -649,8 +708,9 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     p.cand = ctx->pc_ovf;
     {
       Timer t(ctx, &ctx->ms_kpe);
+      const size_t pad_lds = getenv("RMX_PC_PADLDS") ? (size_t)atoi(getenv("RMX_PC_PADLDS")) * 1024 : 0;  // occupancy sweeps: fewer workgroups per CU
       ctx->kpe_kernel = "kpe_pc";
-      hipLaunchKernelGGL(kpe_pc, grid, dim3(256), 0, ctx->stream, p);
+      hipLaunchKernelGGL(kpe_pc, grid, dim3(256), pad_lds, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
   }
@@ -678,7 +738,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     dim3 grid((p.groups + 3) / 4, (ctx->H + 2 * p.rows_per_strip - 1) / (2 * p.rows_per_strip));
     {
       Timer t(ctx, &ctx->ms_kpe);
-      static const size_t pad_lds = getenv("RMX_BS_PADLDS") ? (size_t)atoi(getenv("RMX_BS_PADLDS")) * 1024 : 0;  // experiment: fewer workgroups per CU
+      const size_t pad_lds = getenv("RMX_BS_PADLDS") ? (size_t)atoi(getenv("RMX_BS_PADLDS")) * 1024 : 0;  // experiment: fewer workgroups per CU
       ctx->kpe_kernel = ring ? "kpe_bs_ring" : "kpe_bs";
       if (ring) hipLaunchKernelGGL(kpe_bs_ring, grid, dim3(256), pad_lds, ctx->stream, p);  // (keeps no candidate words)
       else hipLaunchKernelGGL(kpe_bs, grid, dim3(256), p.rows_per_strip * 256 * sizeof(uint32_t) + pad_lds, ctx->stream, p);

@@ -471,7 +471,12 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // (uniform: the frame walk runs on the scalar unit)
   const uint32_t b = blit_tile_of_block();
   const uint32_t group = b % p.groups_x, tcol = group * 4 + wv;
-  if (tcol >= p.tiles_x) return;  // (no barriers in this kernel)
+  // Waves without a tile leave here, BEFORE the first barrier: refill() below synchronises the workgroup
+  // (RMX_BLIT_SYNC), and s_barrier counts only the waves that have not ended.  The invariant the barriers rest
+  // on: every wave that stays walks the SAME list (its workgroup's column bin, both passes) and executes exactly
+  // 64 / RMX_BLIT_SYNC barriers per batch of 64 records, whatever its tile matches — no per-wave exit or
+  // per-wave list may be added below without taking the barriers out.
+  if (tcol >= p.tiles_x) return;
   const int Y0 = (int)(b / p.groups_x) * R;
   const int X0 = (int)(tcol * BL_TW), X = X0 + (int)lane;
   const int W = (int)p.W, H = (int)p.H;

@@ -249,6 +249,16 @@ def test_ful_files_round_trip_through_hbm(gpu, tmp_path):
         fl = lines[1 + k].split()
         assert [int(fl[2]), int(fl[3]), int(fl[5]), int(fl[6]), int(fl[8])] == [w, h, zx, zy, nf]
         assert (dst / str(k)).read_bytes() == g[f"file{k}"].tobytes()
+    # a truncated file, and one whose header asks for more dots than any file holds: an error that names the
+    # file — not a shortened list, not an allocation of the header's size
+    whole = g["file0"].tobytes()
+    for k, blob in enumerate((whole[: len(whole) // 2], np.array([1 << 40, 1 << 40], np.uint64).tobytes() + whole[16:])):
+        bad = tmp_path / f"bad{k}"
+        bad.mkdir()
+        (bad / "0").write_bytes(whole)
+        (bad / "1").write_bytes(blob)
+        r = subprocess.run([exe, str(bad), "1", "1", "ful", str(dst)], capture_output=True, text=True)
+        assert r.returncode != 0 and "ful::read" in r.stderr and str(bad / "1") in r.stderr, r.stderr[-500:]
 
 
 def test_ful_python_round_trip(gpu, tmp_path):
