@@ -53,6 +53,7 @@ KERNEL_NOTES = {
     "kpe_pc": "candidate test by pairwise rank comparison on bit planes, 32 pixels per lane operation; 5x5 finish rolled into the row "
               "loop, windows from an LDS ring of the streamed rows; the median plane = the input rows from that ring with the "
               "candidates' nibbles patched",
+    "kpe_pc_dense": "kpe_pc with the median patches of eight passes per roll in registers (dense streams)",
     "kpe_bs_ring": "3x3 rank selection on bit planes, 32 pixels per lane operation, + 5x5 finish rolled into the row loop, windows "
                    "from an LDS ring of the streamed rows",
     "kpe_bs": "3x3 rank selection on bit planes, 32 pixels per lane operation, + 5x5 finish of the workgroup's own candidates",
@@ -159,8 +160,21 @@ def time_stream(torch, frames, W, H, kmax, steps, lanes, truth=None):
     return rec
 
 
-def other_workloads(torch, args):
-    """The BASELINE.json workloads beside the headline's, one GPU, timed in this run."""
+def profile_files(name):
+    """Committed rocprofv3 summaries of workload `name` at HEAD (tools/profile_round_r04.sh): the latest of each kind."""
+    import glob
+
+    out = {}
+    for kind, pat in (("kernel_stats", f"*_{name}_kernel_stats.csv"), ("pmc", f"*_{name}_pmc_*.json")):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        if files:
+            out[kind] = os.path.relpath(files[-1], ROOT)
+    return out or None
+
+
+def other_workloads(torch, args, only=None):
+    """The BASELINE.json workloads beside the headline's, one GPU, timed in this run (`only`: just that one — what
+    tools/profile_round_r04.sh runs under rocprofv3 for the per-workload kernel statistics)."""
     from remap_amd.pipeline import Aligner
     from remap_amd.splice import splice
     from remap_amd.synth import rooms_v1, scroller_v1, upscale2
@@ -168,33 +182,43 @@ def other_workloads(torch, args):
     res = {}
     n = args.frames
     steps = max(4, args.steps // 2)
-    fr, truth = scroller_v1(n, W, H, dens=40)
-    res["dense"] = dict(time_stream(torch, torch.from_numpy(fr).cuda(), W, H, 2048, steps, args.lanes, truth),
-                        workload=f"{n} frames 320x240 scroller-v1 dens 40 (configs[1], dense variant)")
-    del fr
+    want = lambda name: only in (None, name)
+    if want("dense"):
+        fr, truth = scroller_v1(n, W, H, dens=40)
+        res["dense"] = dict(time_stream(torch, torch.from_numpy(fr).cuda(), W, H, 2048, steps, args.lanes, truth),
+                            workload=f"{n} frames 320x240 scroller-v1 dens 40 (configs[1], dense variant)")
+        del fr
     # configs[3]: 640x480, a stream generated at that size and the pixel-doubled 320x240 stream
-    fr, truth = scroller_v1(n, 640, 480, dens=DENS)
-    d = torch.from_numpy(fr).cuda()
-    del fr
-    res["config4_native"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes, truth),
-                                 workload=f"{n} frames 640x480 scroller-v1 generated at that size (configs[3])")
-    small, _ = scroller_v1(n, W, H, dens=DENS)
-    for i in range(0, n, 1000):  # (upscaled slice by slice: the host copy of the doubled stream would be 3 GB)
-        d[i:i + 1000] = torch.from_numpy(upscale2(small[i:i + 1000])).cuda()
-    res["config4_doubled"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes),
-                                  workload=f"{n} frames 640x480 = scroller-v1 pixel-doubled (configs[3] 'upscaled capture'; a doubled "
-                                           "patch rarely yields keypoints — ~4 per frame — so about one frame in ten opens a new fragment)")
-    al = Aligner(640, 480, kmax=4096)
-    al.align(d, blit=True)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(3):
+    if want("config4_native"):
+        fr, truth = scroller_v1(n, 640, 480, dens=DENS)
+        d = torch.from_numpy(fr).cuda()
+        del fr
+        res["config4_native"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes, truth),
+                                     workload=f"{n} frames 640x480 scroller-v1 generated at that size (configs[3])")
+        del d
+    if want("config4_doubled"):
+        small, _ = scroller_v1(n, W, H, dens=DENS)
+        d = torch.empty((n, 480, 640), dtype=torch.uint8, device="cuda")
+        for i in range(0, n, 1000):  # (upscaled slice by slice: the host copy of the doubled stream would be 3 GB)
+            d[i:i + 1000] = torch.from_numpy(upscale2(small[i:i + 1000])).cuda()
+        res["config4_doubled"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes),
+                                      workload=f"{n} frames 640x480 = scroller-v1 pixel-doubled (configs[3] 'upscaled capture'; a doubled "
+                                               "patch rarely yields keypoints — ~4 per frame — so about one frame in ten opens a new fragment)")
+        al = Aligner(640, 480, kmax=4096)
         al.align(d, blit=True)
-    torch.cuda.synchronize()
-    res["config4_doubled"]["frames_per_s_with_blit"] = n * 3 / (time.perf_counter() - t0)
-    al.close()
-    del d, small
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            al.align(d, blit=True)
+        torch.cuda.synchronize()
+        res["config4_doubled"]["frames_per_s_with_blit"] = n * 3 / (time.perf_counter() - t0)
+        al.close()
+        del d, small
     torch.cuda.empty_cache()
+    for name, rec in res.items():
+        rec["profiles"] = profile_files(name)
+    if not want("config5"):
+        return res
     # configs[4]: rooms-v1, 50 000 frames on one GPU: collect with the canvas blit, then fgs::splice
     n5 = 5 * n
     fr, _, _ = rooms_v1(n5, W, H, n_rooms=64, dens=DENS, seed=7)
@@ -225,7 +249,7 @@ def other_workloads(torch, args):
                       "frames": n5, "value": n5 / t_collect, "unit": "frames/s (collect with canvas blit)",
                       "frames_per_s_alignment_only": n5 / t_align, "fragments_collected": nf, "fragments_spliced": len(spliced),
                       "initial_pairs": nf * (nf - 1) // 2, "splice_s": t_splice,
-                      "pair_matches_per_s": nf * (nf - 1) // 2 / t_splice}
+                      "pair_matches_per_s": nf * (nf - 1) // 2 / t_splice, "profiles": profile_files("config5")}
     al.close()
     return res
 
@@ -247,6 +271,8 @@ def main():
     ap.add_argument("--no-workloads", action="store_true", help="skip the other BASELINE.json workloads (dense, 640x480, rooms)")
     ap.add_argument("--headline-only", action="store_true", help="only the headline's steps (and the one-lane repeat): no tiers B/C, host-fed "
                                                                    "rate, copy rates or earlier kernels — for kernel traces of the timed region")
+    ap.add_argument("--only-workload", default=None, help="dense | config4_native | config4_doubled | config5: time just that workload "
+                                                          "and print it (for rocprofv3 runs of one workload)")
     ap.add_argument("--cpu-frames", type=int, default=10000)
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL) on a multi-GPU node; gloo only to rehearse the "
                                                       "multi-rank flow on one GPU")
@@ -278,6 +304,9 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the hot path has no CPU fallback")
     L.load()
+    if args.only_workload:
+        print(json.dumps({"workloads": other_workloads(torch, args, only=args.only_workload)}), flush=True)
+        return
 
     n_local = args.frames
     n_total = n_local * world

@@ -58,6 +58,8 @@ struct rmx_ctx {
   // kernel's place where a frame's rows fill a wave: widths that are multiples of 32 whose 32-pixel chunks divide
   // 64 with at most eight lanes idle.  RMX_KPE_PC=0: kpe_bs_ring.  pc_ra: rows per strip (one strip per wave).
   bool kpe_pc = false;
+  bool pc_dense = false;  // kpe_pc<8> (set with bs_ring by the density of the batch before; RMX_PC_DENSE=0/1 forces it)
+  int pc_dense_forced = -1;
   uint32_t pc_ra = 30, pc_ra_short = 30, pc_long_pct = 0;  // RMX_PC_PLAN=long,short,percent
   uint32_t* pc_ovf = nullptr;  // PC_OVF_DWORDS per wave of the launch, all zero between launches
   size_t pc_ovf_bytes = 0;
@@ -345,6 +347,7 @@ int rmx_ctx_create(int device, uint32_t width, uint32_t height, uint32_t grid_w,
   if (const char* e = getenv("RMX_BS_RING")) ctx->bs_ring_forced = atoi(e) != 0, ctx->bs_ring = atoi(e) != 0;
   ctx->kpe_pc = ctx->kpe_bs && width % 32 == 0 && width / 32 <= 64 && 64 % (width / 32) <= 8;
   if (const char* e = getenv("RMX_KPE_PC")) ctx->kpe_pc = ctx->kpe_pc && atoi(e) != 0;
+  if (const char* e = getenv("RMX_PC_DENSE")) ctx->pc_dense_forced = atoi(e) != 0, ctx->pc_dense = atoi(e) != 0;
   if (const char* e = getenv("RMX_PC_RA")) ctx->pc_ra = ctx->pc_ra_short = (uint32_t)std::max(6, atoi(e) / 6 * 6);
   if (const char* e = getenv("RMX_PC_PLAN")) {
     unsigned a = 0, b = 0, c = 0;
@@ -393,10 +396,14 @@ int rmx_ctx_destroy(rmx_ctx* ctx) {
 
 // status[15] of the batch whose status words just came back: keypoints of its sampled frames
 static void kpe_note_density(rmx_ctx* ctx, uint32_t sampled_keypoints) {
-  if (ctx->bs_ring_forced >= 0 || ctx->n_last == 0 || ctx->kmax > KPE_KMAX_LDS) return;  // (kpe_table_big does not sample)
+  if (ctx->n_last == 0 || ctx->kmax > KPE_KMAX_LDS) return;  // (kpe_table_big does not sample)
   const uint64_t frames = (ctx->n_last + 31) / 32;
-  // (measured crossover at 320x240: kpe_bs_ring between 173 and 360 keypoints per frame; kpe_pc: +20 % at 170, -3 % at 450, -45 % at 1 100)
-  ctx->bs_ring = (uint64_t)sampled_keypoints * (ctx->kpe_pc ? 200 : 320) <= frames * ctx->W * ctx->H;
+  // kpe_pc: the instance with eight register passes from ~250 keypoints per 320x240 frame on (measured: 4 passes
+  // 0.347 / 0.37 / 0.62 / 1.73 ms per 10 000 frames at 67 / 170 / 450 / 1 100 keypoints per frame, 8 passes 0.353 / - / 0.53 / 0.85)
+  if (ctx->pc_dense_forced < 0) ctx->pc_dense = (uint64_t)sampled_keypoints * 300 > frames * ctx->W * ctx->H;
+  if (ctx->bs_ring_forced >= 0) return;
+  // kpe_bs_ring against kpe_bs (widths kpe_pc does not take): measured crossover at 320x240 between 173 and 360 keypoints per frame
+  ctx->bs_ring = (uint64_t)sampled_keypoints * 320 <= frames * ctx->W * ctx->H;
 }
 
 int rmx_kpe_take_turns(rmx_ctx* const* ctxs, uint32_t n) {
@@ -672,7 +679,7 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
   }
   // the two-kernel form (RMX_KPE_PAIR) and the sub-batch experiments exist for kpe_main / kpe_finish only
   const bool use_bs = !ctx->fused.ok && ctx->kpe_bs && !overlap && getenv("RMX_KPE_PAIR") == nullptr;
-  const bool use_pc = use_bs && ctx->bs_ring && ctx->kpe_pc;
+  const bool use_pc = use_bs && ctx->kpe_pc && (ctx->bs_ring || ctx->bs_ring_forced < 0);  // (RMX_BS_RING=0 forces kpe_bs)
   if (use_pc) {
     KpeParams p{};
     p.frames = frames;
@@ -709,8 +716,10 @@ int rmx_kpe_batch(rmx_ctx* ctx, const uint8_t* frames, uint32_t n, uint8_t* medi
     {
       Timer t(ctx, &ctx->ms_kpe);
       const size_t pad_lds = getenv("RMX_PC_PADLDS") ? (size_t)atoi(getenv("RMX_PC_PADLDS")) * 1024 : 0;  // occupancy sweeps: fewer workgroups per CU
-      ctx->kpe_kernel = "kpe_pc";
-      hipLaunchKernelGGL(kpe_pc, grid, dim3(256), pad_lds, ctx->stream, p);
+      // (the dense instance keeps the patches of eight passes per roll in registers, the sparse one of four)
+      ctx->kpe_kernel = ctx->pc_dense ? "kpe_pc_dense" : "kpe_pc";
+      if (ctx->pc_dense) hipLaunchKernelGGL(kpe_pc<8>, grid, dim3(256), pad_lds, ctx->stream, p);
+      else hipLaunchKernelGGL(kpe_pc<4>, grid, dim3(256), pad_lds, ctx->stream, p);
     }
     RMX_HIP(hipGetLastError());
   }

@@ -35,7 +35,10 @@ namespace rmx {
 
 constexpr uint32_t PC_RING = 7;    // ring rows: a roll reads rows k0 - 2 .. k0 + 4
 constexpr uint32_t PC_STASH = 64;  // keypoints a wave holds before it encodes and appends them
-constexpr uint32_t PC_REG_PASSES = 4;  // passes of a roll whose patches wait in registers (an average roll has 64 candidates)
+// Passes (of 64 candidates) of a roll whose patches wait in registers: 4 for sparse streams (an average roll has 60
+// candidates; two registers per pass), 8 for dense ones (460 per roll at 1 100 keypoints per frame; what does not
+// fit goes through global atomics: 1.73 ms per 10 000 dense frames with 4, 0.85 with 8 — and 2 % more on the sparse
+// stream, whose rounds pay a select per pass).  api.hip picks by the density of the batch before.
 constexpr uint32_t PC_OVF_DWORDS = 2 * 3 * 64 * 4;  // per wave: [generation][row of the roll][lane][dword of the ring row]
 #ifndef RMX_PC_DEPTH
 #define RMX_PC_DEPTH 2  // rows in flight
@@ -110,7 +113,9 @@ __device__ __forceinline__ uint32_t pc_scan(uint32_t v) {
   return v;
 }
 
+template <uint32_t NP>
 struct PcRoll {
+  static constexpr uint32_t PC_REG_PASSES = NP;
   PcWaveLds* L;
   uint32_t* ovf;  // this wave's PC_OVF_DWORDS of global memory (all zero between launches)
   uint32_t lane, ya, RA, f0, Wc, magic;  // magic: lane / Wc == lane * magic >> 16
@@ -123,7 +128,8 @@ struct PcRoll {
 };
 
 // weight, code bytes and table rows for the stashed keypoints
-__device__ __forceinline__ void pc_flush(const KpeParams& p, PcRoll& R) {
+template <uint32_t NP>
+__device__ __forceinline__ void pc_flush(const KpeParams& p, PcRoll<NP>& R) {
   PcWaveLds& L = *R.L;
   const uint32_t lane = R.lane, n = R.nst;
   if (n == 0) return;  // uniform
@@ -174,7 +180,8 @@ __device__ __forceinline__ void pc_patch(PcWaveLds& L, uint32_t e, uint32_t slot
 }
 
 // one ring row (final: every patch applied) -> the median plane
-__device__ __forceinline__ void pc_store_row(const KpeParams& p, const PcRoll& R, const rsrc_t& rout, uint32_t slot, int y) {
+template <uint32_t NP>
+__device__ __forceinline__ void pc_store_row(const KpeParams& p, const PcRoll<NP>& R, const rsrc_t& rout, uint32_t slot, int y) {
   const uint32_t* row = &R.L->ring[slot][0][0];
   u32x4 va = {0, 0, 0, 0}, vb = {0, 0, 0, 0};
   if (y >= 2 && y + 5 <= (int)p.H) {  // (uniform) processed rows: [2, H-5] (kpe.hpp:268); the others are zero
@@ -194,7 +201,9 @@ __device__ __forceinline__ void pc_store_row(const KpeParams& p, const PcRoll& R
 
 // The candidates of strip rows k0, k0 + 1, k0 + 2 (words w0..w2 of every lane: bit x = pixel x of the lane's chunk);
 // ring rows k0 - 2 .. k0 + 4 are in LDS.  Afterwards rows k0 - 2 .. k0 are final and stored.
-__device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsrc_t& rout, uint32_t w0, uint32_t w1, uint32_t w2, int k0) {
+template <uint32_t NP>
+__device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll<NP>& R, const rsrc_t& rout, uint32_t w0, uint32_t w1, uint32_t w2, int k0) {
+  constexpr uint32_t PC_REG_PASSES = NP;
   PcWaveLds& L = *R.L;
   const uint32_t lane = R.lane;
   const uint32_t c = (uint32_t)(__builtin_popcount(w0) + __builtin_popcount(w1) + __builtin_popcount(w2));
@@ -353,7 +362,9 @@ __device__ __forceinline__ void pc_roll(const KpeParams& p, PcRoll& R, const rsr
   R.gen ^= 1u;
 }
 
+template <uint32_t NP>
 __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
+  constexpr uint32_t PC_REG_PASSES = NP;
   __shared__ PcWaveLds s_wave[4];
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.status[15] = 0;  // (keypoints of sampled frames: kpe_table)
 #if defined(RMX_PC_PRIO)  /* experiment: issue ahead of the other streams' small kernels */
@@ -382,7 +393,7 @@ __global__ __launch_bounds__(256, RMX_PC_WGS) void kpe_pc(KpeParams p) {
   if (!lane_ok) maskx = 0;
   // Memory lanes: the first 16-byte access of a row covers chunks 0 .. 31 (lane i: half i & 1 of chunk i / 2), the
   // second chunks 32 .. 63 — every instruction touches whole 32-byte sectors.
-  PcRoll roll;
+  PcRoll<NP> roll;
   uint32_t ld_a, ld_b;
   {
     const uint32_t half = lane & 1u;

@@ -9,14 +9,15 @@ from remap_amd.synth import scroller_v1, upscale2
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bs", "bs-halo", "ring", "ring-halo", "pc", "pc-short", "mf"])
+@pytest.fixture(params=["bs", "bs-halo", "ring", "ring-halo", "pc", "pc-short", "pc-dense", "mf"])
 def kpe_path(request, monkeypatch):
     """The extraction kernels a context may pick (read from the environment when it is created): kpe_bs
     (3x3 pass on bit planes, widths that are multiples of 16; whole image rows per wave, or 62 chunks + 2
     halo lanes with short strips), kpe_bs_ring (the same streaming pass with the finish rolled into the row loop,
     which a context otherwise picks by the density of the batch before), kpe_pc (kpe_pc.hip: candidates by pairwise
     comparison, medians patched in the LDS ring; takes the ring kernel's place where a frame's rows fill a wave — other
-    widths fall through to kpe_bs_ring — with strips of 48 and of 6 rows) and kpe_mf (any width)."""
+    widths fall through to kpe_bs_ring — with strips of 30 and of 6 rows, and its instance for dense streams, which
+    keeps the patches of eight passes per roll in registers instead of four) and kpe_mf (any width)."""
     if request.param == "mf":
         monkeypatch.setenv("RMX_KPE_BS", "0")
     else:
@@ -24,6 +25,8 @@ def kpe_path(request, monkeypatch):
         monkeypatch.setenv("RMX_KPE_PC", "1" if request.param.startswith("pc") else "0")
     if request.param == "pc-short":
         monkeypatch.setenv("RMX_PC_RA", "6")
+    if request.param.startswith("pc"):
+        monkeypatch.setenv("RMX_PC_DENSE", "1" if request.param == "pc-dense" else "0")
     if request.param.endswith("-halo"):
         monkeypatch.setenv("RMX_BS_HALO", "1")
         monkeypatch.setenv("RMX_BS_RA", "6")
@@ -194,40 +197,48 @@ def test_kpe_bs_shapes(gpu, kpe_path):
 
 
 def test_kpe_paths_agree_on_a_long_batch(gpu, monkeypatch):
-    """kpe_bs, kpe_bs_ring and kpe_mf on 3 001 frames: medians, counts and tables byte for byte (the batch is not a
-    multiple of the three rows a wave holds; dense frames so every workgroup hands out > 2 048 candidates and every
-    wave of the ring kernel appends its records in several batches); and a context left to itself picks the ring
-    kernel after a sparse batch, the workgroup finish after a dense one — same bytes either way."""
+    """kpe_bs, kpe_bs_ring, kpe_mf and both instances of kpe_pc on 3 001 frames: medians, counts and tables byte for
+    byte (the batch is not a multiple of the rows a wave holds; dense frames so every workgroup hands out > 2 048
+    candidates, every wave of the ring kernels appends its records in several batches and kpe_pc's rolls overflow
+    the registers of its sparse instance); and a context left to itself runs kpe_pc, its dense instance after a
+    dense batch, the sparse one again after a sparse batch — same bytes either way."""
     import torch
 
     frames, _ = scroller_v1(3001, dens=40)
     d = torch.from_numpy(frames).cuda()
     res = []
-    for bs, ring in (("1", "0"), ("1", "1"), ("0", "0")):
+    names = ("kpe_bs", "kpe_bs_ring", "kpe_mf", "kpe_pc", "kpe_pc_dense")
+    for (bs, ring, pc, dense), name in zip((("1", "0", "0", "0"), ("1", "1", "0", "0"), ("0", "0", "0", "0"), ("1", "1", "1", "0"), ("1", "1", "1", "1")), names):
         monkeypatch.setenv("RMX_KPE_BS", bs)
         monkeypatch.setenv("RMX_BS_RING", ring)
+        monkeypatch.setenv("RMX_KPE_PC", pc)
+        monkeypatch.setenv("RMX_PC_DENSE", dense)
         ctx = L.Context(320, 240, kmax=4096)
         med, desc, kc = ctx.kpe(d)
-        assert ctx.kpe_status()[0] == 0
+        assert ctx.kpe_status()[0] == 0 and ctx.kpe_kernel() == name
         res.append((med.clone(), desc.clone(), kc.clone()))
         ctx.close()
     k = res[0][2].cpu().numpy()
     a = res[0][1].cpu().numpy()
-    for other, name in ((res[1], "kpe_bs_ring"), (res[2], "kpe_mf")):
+    for other, name in zip(res[1:], names[1:]):
         assert torch.equal(res[0][0], other[0]), f"medians differ between kpe_bs and {name}"
         assert torch.equal(res[0][2], other[2]), "keypoint counts differ"
         b = other[1].cpu().numpy()
         assert all(a[i, : k[i]].tobytes() == b[i, : k[i]].tobytes() for i in range(len(k))), f"tables differ ({name})"
     # the choice by density (kpe_table samples every 32nd frame's count; read back with the status words)
     monkeypatch.delenv("RMX_BS_RING")
+    monkeypatch.delenv("RMX_KPE_PC")
+    monkeypatch.delenv("RMX_PC_DENSE")
     monkeypatch.setenv("RMX_KPE_BS", "1")
     monkeypatch.setenv("RMX_TIMING", "1")
     sparse, _ = scroller_v1(640, dens=200)
     ds = torch.from_numpy(sparse).cuda()
     ctx = L.Context(320, 240, kmax=4096)
     ref_sparse = None
-    for blk, want in ((ds, None), (ds, None), (d[:640], None), (d[:640], res[0]), (ds, None)):
+    for blk, want, kernel in ((ds, None, "kpe_pc"), (ds, None, "kpe_pc"), (d[:640], None, "kpe_pc"), (d[:640], res[0], "kpe_pc_dense"),
+                              (ds, None, "kpe_pc_dense"), (ds, None, "kpe_pc")):
         med, desc, kc = ctx.kpe(blk)
+        assert ctx.kpe_kernel() == kernel
         assert ctx.kpe_status()[0] == 0  # (brings the density word back: the NEXT batch's kernel is chosen by it)
         if blk is ds:
             if ref_sparse is None:

@@ -5,9 +5,11 @@ from remap_amd import lib as L
 from remap_amd.synth import scroller_v1
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 dens = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-frames,_ = scroller_v1(n, dens=dens)
+Wf = int(sys.argv[3]) if len(sys.argv) > 3 else 320  # (640 480: BASELINE configs[3], generated at that size)
+Hf = int(sys.argv[4]) if len(sys.argv) > 4 else 240
+frames,_ = scroller_v1(n, Wf, Hf, dens=dens)
 n,H,W = frames.shape
-ctx = L.Context(W,H,kmax=2048)
+ctx = L.Context(W,H,kmax=4096 if W > 320 else 2048)
 d = torch.from_numpy(frames).cuda()
 med = torch.empty_like(d); desc,kc = ctx.alloc_tables(n)
 ctx.kpe(d, med, desc, kc); ctx.sync()
