@@ -34,7 +34,7 @@
 namespace rmx {
 
 constexpr uint32_t PC_RING = 7;    // ring rows: a roll reads rows k0 - 2 .. k0 + 4
-constexpr uint32_t PC_STASH = 64;  // keypoints a wave holds before it encodes and appends them
+constexpr uint32_t PC_STASH = 64;  // keypoints a wave holds before it encodes and appends them (>= 64: a pass may find that many)
 // Passes (of 64 candidates) of a roll whose patches wait in registers: 4 for sparse streams (an average roll has 60
 // candidates; two registers per pass), 8 for dense ones (460 per roll at 1 100 keypoints per frame; what does not
 // fit goes through global atomics: 1.73 ms per 10 000 dense frames with 4, 0.85 with 8 — and 2 % more on the sparse

@@ -16,7 +16,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 dens = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 variants = sys.argv[3:] or ["ring:RMX_BS_RING=1,RMX_KPE_PC=0", "pc48:RMX_BS_RING=1", "pc24:RMX_BS_RING=1,RMX_PC_RA=24",
                             "pc96:RMX_BS_RING=1,RMX_PC_RA=96", "bs:RMX_BS_RING=0"]
-frames, _ = scroller_v1(n, dens=dens)
+frames, _ = scroller_v1(n, int(os.environ.get("ABW", "320")), int(os.environ.get("ABH", "240")), dens=dens)  # ABW / ABH: frame size
 n, H, W = frames.shape
 d = torch.from_numpy(frames).cuda()
 ref = None
@@ -28,7 +28,7 @@ for rnd in range(2):
             k, _, val = kv.partition("=")
             os.environ[k] = val
             keys.append(k)
-        ctx = L.Context(W, H, kmax=2048)
+        ctx = L.Context(W, H, kmax=2048 if W <= 320 else 4096)
         med = torch.empty_like(d)
         desc, kc = ctx.alloc_tables(n)
         ctx.kpe(d, med, desc, kc)
