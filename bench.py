@@ -14,17 +14,19 @@ tables and per-frame offsets are all-gathered over RCCL, and the result is the g
 alignment.  Rank 0 prints ONE JSON line.
 
 The line also carries
-  roofline     — the extraction kernel (the dominant one: 3x3 pass on bit planes and 5x5 finish in one
-                 launch; kpe_bs_ring on this stream, `roofline.kernel` names the one that ran): algorithmic
+  roofline     — the extraction kernel (the dominant one: candidate test on bit planes and 5x5 finish in one
+                 launch; kpe_pc on this stream, `roofline.kernel` names the one that ran): algorithmic
                  bytes (2*W*H + 18*K per frame) / its average launch time from HIP events
                  on the launch stream, against the 8 TB/s HBM peak; `one_block_in_flight` = the same
                  kernel with the chip to itself; `previous_kernels` = kpe_mf (round 2) and the two-kernel
                  form of rounds 1-2a, timed in this run on this box.  Every figure is measured in the run, except
                  `traffic` and `valu_wave_instructions`, which come from the committed rocprofv3 --pmc
                  passes named in `*_source` (counters cannot be read from inside the process);
+  sustained    — the timed region repeated for a second (K-step groups: median / min / max), so the headline does
+                 not rest on one 8-ms window;
   workloads    — the other BASELINE.json workloads, timed in this run (value + the extraction kernel's
-                 roofline fraction each): dense stream, 640x480 native and pixel-doubled, rooms
-                 (collect with canvas blit, then fgs::splice);
+                 roofline fraction each, `profiles`: the committed rocprofv3 summaries of that workload): dense
+                 stream, 640x480 native and pixel-doubled, rooms (collect with canvas blit, then fgs::splice);
   cpu_baseline — the reference's own frc::collector::collect (oracle/_ref, built from
                  /root/reference by oracle/build_ref.sh) or, if that library is absent, the
                  CPU restatement (oracle/), timed on one host core on the same frames; `all_cores` =
@@ -327,7 +329,7 @@ def main():
     frames = torch.from_numpy(frames_host).to(dev)
 
     al = Aligner(W, H, kmax=2048, device=local_rank, dist=dist)
-    # the headline: blocks taken in turn by two lanes (streams), the small kernels of block t beside
+    # the headline: blocks taken in turn by `--lanes` lanes (streams; three by default), the small kernels of block t beside
     # the extraction of block t + 1 (AlignerPipe); `al` (one lane, the default stream) serves the
     # checks and the figures reported beside the headline
     pipe = AlignerPipe(W, H, kmax=2048, device=local_rank, dist=dist, lanes=args.lanes)

@@ -144,14 +144,16 @@ __device__ __forceinline__ uint32_t bs_first_frame(const KpeParams& p, uint32_t 
 // The workgroup-wide finish gathers every candidate's 5x5 window from global memory 12 row steps after the
 // stream read those rows: by then they have left the L2 (0.04 ms of the kernel) — and gathering them INSIDE the
 // row loop is no better, the oldest row of a window is seven steps old.  Here a wave keeps the
-// last eight rows it streamed in LDS, two pixels per byte exactly as planes_from_bytes packs them first (16 B
-// per lane and row for both strips: 8 KB per wave), and every three row steps it finishes the candidates of
+// last SEVEN rows it streamed in LDS, two pixels per byte exactly as planes_from_bytes packs them first (16 B
+// per lane and row for both strips: 7 KB per wave), and every three row steps it finishes the candidates of
 // three rows by itself: hand-out among its own lanes through a list in LDS, windows read from the ring (only the
-// two rows just outside a strip, which the stream never loads, come from global memory: a tenth of a window row
-// in six), stage-1 test, and for the keypoints weight and code bytes at once; finished records wait in a small
+// two rows just outside a strip, which the stream never loads, come from global memory: one window row in
+// thirty), stage-1 test, and for the keypoints weight and code bytes at once; finished records wait in a small
 // per-wave list and are appended to their frames' tables in batches (table rows reserved with one global atomic
-// per frame and batch, all frames in one instruction).  No workgroup barrier is left in the kernel; 52 KB of LDS
-// per workgroup = three workgroups per CU, which costs the streaming pass nothing (measured with padded LDS).
+// per frame and batch, all frames in one instruction).  No workgroup barrier is left in the kernel; 40 960 B of
+// LDS per workgroup and 128 VGPRs = four workgroups per CU (three cost 5 %: tools/ab_ring.sh, round 4).
+// (kpe_pc.hip is this kernel's successor for widths whose rows fill a wave: same ring and roll, the candidate
+// test by pairwise comparison, medians patched in the ring.)
 #ifndef RMX_BSR_ROWS
 #define RMX_BSR_ROWS 7
 #endif
