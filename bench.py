@@ -120,7 +120,7 @@ def pmc_file(n_local, dens, kernel="kpe_bs"):
         return None, None
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_{kernel}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r[0-9][0-9]_[a-z]_pmc_{kernel}.json")))  # (the headline stream's: <round>_<run>_pmc_<kernel>.json)
     if not files:
         return None, None
     try:
@@ -172,6 +172,21 @@ def profile_files(name):
         if files:
             out[kind] = os.path.relpath(files[-1], ROOT)
     return out or None
+
+
+def headline_profiles(kernel_name):
+    """Committed rocprofv3 summaries behind the headline's figures (latest round in profiles/)."""
+    import glob
+
+    def last(pat):
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", pat)))
+        return os.path.relpath(files[-1], ROOT) if files else None
+
+    return {"kernel_stats_of_the_timed_region": last("r[0-9][0-9]_[a-z]_kernel_stats.csv"),
+            "pmc_extraction_kernel": last(f"r[0-9][0-9]_[a-z]_pmc_{kernel_name}.json"),
+            "pmc_fgm_blit_scroller": last("r[0-9][0-9]_[a-z]_blit_pmc_fgm_blit.json"),
+            "drop_in_collector": last("r[0-9][0-9]_time_dropin.txt"),
+            "config4_strip_occupancy_sweep": last("r[0-9][0-9]_config4_strip_sweep_640x480.jsonl")}
 
 
 def other_workloads(torch, args, only=None):
@@ -594,6 +609,7 @@ def main():
                                       + (f", {args.lanes} blocks in flight per GPU (the small kernels of block t beside the extraction of block t+1)"
                                          if args.lanes > 1 else "")},
             "offsets_bit_exact_vs_truth": exact,
+            "profiles": headline_profiles(kernel_name),
             "spin_up": {"seconds": args.spin_up, "untimed_steps": spin_steps,
                         "note": "untimed steps of the same loop between the W warm-up steps and the K timed ones: the device's "
                                 "sustained state (the first K steps after idle run ~8 % slower than all later ones)"},

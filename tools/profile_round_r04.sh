@@ -7,7 +7,7 @@
 #   <tag>_<workload>_kernel_stats.csv     the same for every sub-record's workload (bench.py --only-workload)
 #   <tag>_pmc_kpe_pc.json                 PMC passes of the extraction kernel on the headline stream (FETCH_SIZE, WRITE_SIZE,
 #                                         SQ_INSTS_VALU ... ; separate passes, kernel trace only beside them)
-#   <tag>_dense_pmc_kpe_pc_dense.json, <tag>_config4_native_pmc_kpe_pc.json, <tag>_config5_pmc_fgm_blit.json (scroller blit)
+#   <tag>_dense_pmc_kpe_pc_dense.json, <tag>_config4_native_pmc_kpe_pc.json, <tag>_blit_pmc_fgm_blit.json (the scroller's canvas blit: frames_per_s_with_blit)
 set -e
 TAG=$1
 R=$GRAFT_REPO_ROOT
@@ -41,7 +41,7 @@ PN="10000 200" PD="" pmc pmc_kpe_pc "kpe_pc<4" RMX_PC_DENSE=0
 PN="10000 40" PD="" pmc dense_pmc_kpe_pc_dense "kpe_pc<8" RMX_PC_DENSE=1
 PN="10000 200 640 480" PD="" pmc config4_native_pmc_kpe_pc "kpe_pc<4" RMX_PC_DENSE=0
 bash tools/pmc_blit.sh ${TAG}_blit > $OUT/pmc_blit.log 2>&1 || tail -5 $OUT/pmc_blit.log
-cp gpurun_out/pmc_${TAG}_blit/pmc_fgm_blit.json $OUT/${TAG}_config5_pmc_fgm_blit.json || true
+cp gpurun_out/pmc_${TAG}_blit/pmc_fgm_blit.json $OUT/${TAG}_blit_pmc_fgm_blit.json || true
 rm -rf gpurun_out/pmc_${TAG}_blit
 ls -la $OUT
 head -c 1200 $OUT/${TAG}_bench.json
