@@ -154,6 +154,9 @@ def load():
     lib.rmx_download.argtypes = [vp, vp, vp, sz]
     lib.rmx_download_2d.argtypes = [vp, vp, sz, vp, sz, sz, sz]
     lib.rmx_copy.argtypes = [vp, vp, vp, sz]
+    lib.rmx_upload_pinned.argtypes = [vp, vp, vp, sz]
+    lib.rmx_download_pinned.argtypes = [vp, vp, vp, sz]
+    lib.rmx_download_2d_pinned.argtypes = [vp, vp, vp, sz, sz, sz]
     lib.rmx_memset.argtypes = [vp, vp, C.c_int, sz]
     lib.rmx_version.argtypes = []
     lib.rmx_set_timing.argtypes = [vp, C.c_int]
