@@ -280,6 +280,8 @@ def main():
     ap.add_argument("--dens", type=int, default=DENS)
     ap.add_argument("--lanes", type=int, default=3, help="blocks in flight (AlignerPipe); 1: one stream.  Three: a lane's next block is enqueued "
                     "while its previous chain still runs beside the other lanes' extraction kernels (two: 0.453 ms per step, three: 0.430, four: 0.465)")
+    ap.add_argument("--depth", type=int, default=1, help="buffer sets (contexts) per lane: 2 lets a lane's next block be enqueued before "
+                    "its previous one has been settled")
     ap.add_argument("--spin-up", type=float, default=0.3, help="seconds of untimed steps after the W warm-up steps, before the "
                     "timed region: the device reaches its sustained clocks (0: none)")
     ap.add_argument("--sustain", type=float, default=1.0, help="seconds of further K-step groups after the timed one, reported as "
@@ -347,7 +349,8 @@ def main():
     # the headline: blocks taken in turn by `--lanes` lanes (streams; three by default), the small kernels of block t beside
     # the extraction of block t + 1 (AlignerPipe); `al` (one lane, the default stream) serves the
     # checks and the figures reported beside the headline
-    pipe = AlignerPipe(W, H, kmax=2048, device=local_rank, dist=dist, lanes=args.lanes)
+    pipe = AlignerPipe(W, H, kmax=2048, device=local_rank, dist=dist, lanes=args.lanes, depth=args.depth)
+    slots = args.lanes * args.depth
 
     def barrier():
         if dist is not None:
@@ -374,7 +377,7 @@ def main():
     # The K timed steps are enqueued back to back (defer=True: a stream of blocks, as collect
     # sees it); the host waits ONCE, inside the timed region: finish() returns the last step's
     # fragment count and raises if any of the K steps overflowed a table or a matcher limit.
-    for _ in range(max(args.warmup, 2 * args.lanes)):
+    for _ in range(max(args.warmup, 2 * slots)):
         pipe.align(frames, n_total=n_total)
     pipe.finish()
     # The device needs a few hundred milliseconds of load to reach its sustained state (clocks): the first K steps
@@ -384,10 +387,10 @@ def main():
     spin_steps = 0
     t_spin = time.perf_counter()
     while time.perf_counter() - t_spin < args.spin_up:
-        for _ in range(2 * args.lanes):
+        for _ in range(2 * slots):
             pipe.align(frames, n_total=n_total)
         pipe.finish()
-        spin_steps += 2 * args.lanes
+        spin_steps += 2 * slots
     for lane in pipe.lanes:
         lane.ctx.set_timing(2)
     barrier()

@@ -22,6 +22,7 @@
 #include "kpm_cell.hip"
 #include "fgs_big.hip"
 #include "fgm.hip"
+#include "fgm_bs.hip"
 #include "nic.hip"
 #include "fdf.hip"
 

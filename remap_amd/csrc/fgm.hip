@@ -213,6 +213,11 @@ struct BlitParams {
   uint32_t* col_cnt;  // groups_x + 1: counts, then exclusive offsets (in place)
   uint32_t* col_cur;  // groups_x fill cursors
   uint4* col_list;    // (frame, canvas x, canvas y, -) records, <= n * (W / 256 + 2); nullptr: a short batch, not binned
+  // Order of a group's list (blit_bin_sort): by frame, or class by class of (frame mod `stride`) — then EVERY
+  // group's list runs through the batch in the same order of residues, and two workgroups that need the same frame
+  // (x-neighbouring groups share the lines at their common border) reach it at about the same list position.  The
+  // order of a list has no influence on the result.
+  uint32_t stride;    // 0: the lists stay as the atomics of blit_bin_fill left them (chunks of 64 frames in arbitrary order); 1: frame order
   uint32_t fresh;     // the canvas holds no counts yet and need not be initialised: every dot is WRITTEN (first fold of a
                       // tile without reading, tiles no frame touches write zeros) — no memset, no read of the canvas
 };
@@ -229,6 +234,9 @@ constexpr int BL_TW = 64, BL_GW = 4 * BL_TW;
 constexpr int BL_ROWS = RMX_BL_ROWS, BL_DEPTH = RMX_BL_DEPTH, BL_ROWS_NARROW = 4;
 #ifndef RMX_BLIT_SYNC
 #define RMX_BLIT_SYNC 16  // list positions between two barriers of a workgroup's waves (a divisor of 64; 0: none): 2.17 -> 1.43 GB fetched per 10 000 frames, same time (4: also 1.43 GB, +10 % time)
+#endif
+#ifndef RMX_BLIT_XFOLD
+#define RMX_BLIT_XFOLD 1  // canvas rows cross the memory interface in memory order (BlitCounters::fold_canvas_x)
 #endif
 constexpr uint32_t BL_DIRECT_MAX = 1024;  // batches up to this many frames skip the binning passes
 
@@ -307,6 +315,41 @@ __global__ __launch_bounds__(256) void blit_bin_fill(BlitParams p) {
   }
 }
 
+// One workgroup per group: its list in the order of (frame mod stride, frame).  Lists longer than BIN_SORT_MAX stay
+// as they are.
+constexpr uint32_t BIN_SORT_MAX = 4096;
+__global__ __launch_bounds__(256) void blit_bin_sort(BlitParams p) {
+  __shared__ uint64_t key[BIN_SORT_MAX];
+  __shared__ uint4 rec[BIN_SORT_MAX];
+  const uint32_t g = blockIdx.x, beg = p.col_cnt[g], L = p.col_cnt[g + 1] - beg;
+  if (L < 2 || L > BIN_SORT_MAX) return;  // (uniform)
+  uint32_t n2 = 2;
+  while (n2 < L) n2 <<= 1;
+  const uint32_t per = (p.n + p.stride - 1) / p.stride;
+  for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+    uint64_t k = ~0ull;
+    if (i < L) {
+      const uint4 r = p.col_list[beg + i];
+      rec[i] = r;
+      k = ((uint64_t)(r.x % p.stride) * per + r.x / p.stride) << 16 | i;
+    }
+    key[i] = k;
+  }
+  for (uint32_t k = 2; k <= n2; k <<= 1)
+    for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+      __syncthreads();
+      for (uint32_t i = threadIdx.x; i < n2; i += 256) {
+        const uint32_t ixj = i ^ j;
+        if (ixj > i) {
+          const uint64_t x = key[i], y = key[ixj];
+          if ((x > y) == ((i & k) == 0)) key[i] = y, key[ixj] = x;
+        }
+      }
+    }
+  __syncthreads();
+  for (uint32_t i = threadIdx.x; i < L; i += 256) p.col_list[beg + i] = rec[(uint32_t)key[i] & 0xffffu];
+}
+
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t blit_rsrc(const uint8_t* base, uint32_t bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(base), (short)0, (int)bytes, 0x00020000);
 }
@@ -328,13 +371,15 @@ __device__ __forceinline__ uint32_t add_u16x2(uint32_t a, uint32_t b) {
 }
 
 // R rows x (two nibble words + four byte words) of counters of one lane's canvas column
-template <int R>
+template <int R, bool XF = false>
 struct BlitCounters {
   uint32_t nib[R][2], byt[R][4];
   uint32_t in_nib, in_byt;  // frames counted since the last fold (uniform)
   bool wrote;               // this tile's dots have been stored once (uniform)
+  uint4* xb;                // 128 x 16 bytes of the wave's LDS: canvas rows in memory order (nullptr: every lane stores its own dot)
 
-  __device__ __forceinline__ void clear() {
+  __device__ __forceinline__ void clear(uint4* xb_ = nullptr) {
+    xb = xb_;
     wrote = false;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
@@ -344,7 +389,70 @@ struct BlitCounters {
     in_nib = in_byt = 0;
   }
   __device__ __forceinline__ void add(int r, uint32_t c, uint32_t one) { blit_count(nib[r][0], nib[r][1], c, one); }
+  // The canvas side in MEMORY ORDER (fgm_blit: xb = 2 KB of the wave's LDS).  A lane owns a column, i.e. one dot of
+  // 32 bytes per row: stored by its owner, a row of the tile is two instructions of 16 bytes per lane at a stride
+  // of 32 — half of every 32-byte sector per instruction.  Here the wave's LDS turns the row round: lane i moves
+  // 16-byte piece i of the row's first 32 dots and piece i of the next 32 (two instructions of 1 KB, contiguous),
+  // the owners read / write their dots in LDS.
+  __device__ __forceinline__ void fold_canvas_x(const BlitParams& p, int X, int Y0, uint4* xb) {
+    typedef unsigned int u32x4 __attribute__((__vector_size__(4 * sizeof(unsigned int))));
+    const uint32_t lane = threadIdx.x & 63u;
+    const int X0 = X - (int)lane;
+    // the tile's R rows through a buffer descriptor at its first dot: row offsets are scalar, a lane's two
+    // offsets are all the addressing that lives in vector registers; pieces right of the canvas get an offset the
+    // range check drops
+    const uint32_t row_bytes = p.cw * 32u;
+    const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
+        p.canvas + ((size_t)Y0 * p.cw + (size_t)X0) * 8, (short)0, (int)min((uint64_t)R * row_bytes, (uint64_t)0x7fffffffu), 0x00020000);
+    const uint32_t vo0 = X0 + (int)(lane >> 1) < (int)p.cw ? lane * 16u : 0x80000000u;
+    const uint32_t vo1 = X0 + 32 + (int)(lane >> 1) < (int)p.cw ? 1024u + lane * 16u : 0x80000000u;
+    const bool rd = !p.fresh || wrote;
+    auto wsync = [&]() {  // (LDS operations of a wave execute in order; this keeps the compiler from moving them)
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    u32x4* xv = reinterpret_cast<u32x4*>(xb);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int Y = Y0 + r;
+      if (Y < (int)p.ch) {  // (uniform)
+        const uint32_t so = (uint32_t)r * row_bytes;
+        uint4 a = make_uint4(0, 0, 0, 0), c = a;
+        if (rd) {
+          xv[lane] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo0, so, 0);
+          xv[64 + lane] = __builtin_amdgcn_raw_buffer_load_b128(crs, vo1, so, 0);
+          wsync();
+          a = xb[2 * lane], c = xb[2 * lane + 1];
+          wsync();
+        }
+        const uint32_t e0 = byt[r][0], o0 = byt[r][1], e1 = byt[r][2], o1 = byt[r][3];
+        a.x = add_u16x2(a.x, __builtin_amdgcn_perm(o0, e0, 0x0c040c00u));
+        a.y = add_u16x2(a.y, __builtin_amdgcn_perm(o0, e0, 0x0c050c01u));
+        a.z = add_u16x2(a.z, __builtin_amdgcn_perm(o0, e0, 0x0c060c02u));
+        a.w = add_u16x2(a.w, __builtin_amdgcn_perm(o0, e0, 0x0c070c03u));
+        c.x = add_u16x2(c.x, __builtin_amdgcn_perm(o1, e1, 0x0c040c00u));
+        c.y = add_u16x2(c.y, __builtin_amdgcn_perm(o1, e1, 0x0c050c01u));
+        c.z = add_u16x2(c.z, __builtin_amdgcn_perm(o1, e1, 0x0c060c02u));
+        c.w = add_u16x2(c.w, __builtin_amdgcn_perm(o1, e1, 0x0c070c03u));
+        xb[2 * lane] = a, xb[2 * lane + 1] = c;
+        wsync();
+        const u32x4 m0 = xv[lane], m1 = xv[64 + lane];
+        wsync();
+        // (as in kpe_bs / kpe_pc: nothing may be scheduled between a 16-byte store with a scalar offset and the
+        // wait states behind it — tools/check_store_hazard.py)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_raw_buffer_store_b128(m0, crs, vo0, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(m1, crs, vo1, so, 0);
+        asm volatile("s_nop 1");
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      byt[r][0] = byt[r][1] = byt[r][2] = byt[r][3] = 0;
+    }
+    in_byt = 0;
+    wrote = true;
+  }
   __device__ __forceinline__ void fold_canvas(const BlitParams& p, int X, int Y0) {
+    if constexpr (XF) return fold_canvas_x(p, X, Y0, xb);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       const int Y = Y0 + r;
@@ -484,8 +592,14 @@ __global__ __launch_bounds__(256) void fgm_blit(BlitParams p) {
   const int lrow = (int)(lane >> 2), lpiece = (int)(lane & 3u) * 16;
   const uint32_t lane_off = (uint32_t)lrow * (uint32_t)W + (uint32_t)lpiece;  // this lane's 16 bytes within the R x 64 window
 
+#if RMX_BLIT_XFOLD
+  __shared__ uint4 xfold[4][128];
+  BlitCounters<R, true> cnt;
+  cnt.clear(xfold[wv]);
+#else
   BlitCounters<R> cnt;
   cnt.clear();
+#endif
 
   // ---- the frame walk.  64 records at a time: lane i tests record i against the tile and works
   // out everything a frame needs as a vector operation (once per 64 frames, not per frame):

@@ -536,14 +536,19 @@ class AlignerPipe:
     shared group lane B's boundary all-gather — which waits for lane B's extraction kernel — would sit in front
     of lane A's scan-summary all-gather and the lanes would serialise."""
 
-    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2, turns=True):
+    def __init__(self, width, height, kmax=2048, device=0, dist=None, group=None, lanes=2, turns=True, depth=1):
+        """lanes: HIP streams; depth: Aligners (contexts, buffer sets) per stream, taken in turn — with depth 2 a
+        stream's next block is enqueued while its previous one is still unsettled (the device never waits for the
+        host's settle of two steps ago), and still only ONE other chain runs beside an extraction kernel."""
         import torch
 
         self.torch = torch
         self.device = torch.device("cuda", device)
-        self.streams = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        base = [torch.cuda.Stream(self.device) for _ in range(lanes)]
+        self.streams = [base[i % lanes] for i in range(lanes * depth)]  # (aligner i runs on stream i % lanes)
+        self.nstreams, self.depth = lanes, depth
         self.lanes = []
-        self.groups = lane_groups(dist, group, lanes)
+        self.groups = lane_groups(dist, group, lanes * depth)
         for s, g in zip(self.streams, self.groups):
             with torch.cuda.stream(s):  # (a Context adopts the stream that is current when it is made)
                 self.lanes.append(Aligner(width, height, kmax=kmax, device=device, dist=dist, group=g))
@@ -553,7 +558,7 @@ class AlignerPipe:
         # reports the free-running rate beside it
         self.set_turns(turns)
         self._turn = 0
-        self._pending = [None] * lanes
+        self._pending = [None] * (lanes * depth)
 
     def set_turns(self, on):
         """Extraction kernels of the lanes one after the other (rmx_kpe_take_turns) or free-running."""

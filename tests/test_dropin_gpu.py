@@ -367,3 +367,41 @@ def test_splice_drop_in_fragments_beyond_2048_keypoints(gpu, tmp_path):
     for no, p in pos.items():
         O.orc_fgm_blit(can, (0, 0), stream[no], p)
     assert int(fl[11]) == poly_sum(can)
+
+
+def test_pinned_link_copies_round_trip(gpu):
+    """rmx_upload_pinned / rmx_download_pinned / rmx_download_2d_pinned (copies across PCIe by a few workgroups of the
+    context's stream, for page-locked host memory): every size and alignment — 16-byte bodies, byte tails, unaligned
+    ends — and packed rows equal to what rmx_download_2d's DMA path gives."""
+    import ctypes as C
+
+    import torch
+
+    ctx = L.Context(320, 240)
+    lib, h = ctx.lib, ctx.h
+    rng = np.random.default_rng(3)
+    cap = 3 << 20
+    host = C.c_void_p()
+    back = C.c_void_p()
+    assert lib.rmx_malloc_host(h, cap, C.byref(host)) == 0 and lib.rmx_malloc_host(h, cap, C.byref(back)) == 0
+    hsrc = np.ctypeslib.as_array((C.c_uint8 * cap).from_address(host.value))
+    hdst = np.ctypeslib.as_array((C.c_uint8 * cap).from_address(back.value))
+    hsrc[:] = rng.integers(0, 256, cap, dtype=np.uint8)
+    dev = torch.zeros(cap + 64, dtype=torch.uint8, device="cuda")
+    for nbytes, so, do in ((1, 0, 0), (15, 3, 5), (16, 0, 0), (4097, 16, 32), (1 << 20, 0, 16), (cap - 7, 7, 1), (cap, 0, 0)):
+        dev.zero_()
+        hdst[:] = 0
+        assert lib.rmx_upload_pinned(h, dev.data_ptr() + do, host.value + so, nbytes) == 0
+        assert lib.rmx_download_pinned(h, back.value + so, dev.data_ptr() + do, nbytes) == 0
+        ctx.sync()
+        assert np.array_equal(dev[do:do + nbytes].cpu().numpy(), hsrc[so:so + nbytes]), (nbytes, so, do)
+        assert np.array_equal(hdst[so:so + nbytes], hsrc[so:so + nbytes]) and not hdst[so + nbytes:so + nbytes + 64].any()
+    # packed rows: 300 rows of 54 bytes out of a pitch of 90
+    rows, width, pitch = 300, 54, 90
+    src = torch.from_numpy(rng.integers(0, 256, rows * pitch, dtype=np.uint8)).cuda()
+    assert lib.rmx_download_2d_pinned(h, back.value, src.data_ptr(), pitch, width, rows) == 0
+    ctx.sync()
+    want = src.cpu().numpy().reshape(rows, pitch)[:, :width].reshape(-1)
+    assert np.array_equal(hdst[: rows * width], want)
+    assert lib.rmx_free_host(h, host) == 0 and lib.rmx_free_host(h, back) == 0
+    ctx.close()
