@@ -37,6 +37,9 @@ constexpr uint32_t BB_FLUSH_PAIRS = 120;      // 240 frames: the 8-bit counters 
 #define RMX_BB_DEPTH 4                        // pairs of frames in a wave's pipe (LDS-DMA ring: 2 KB per pair and wave); divides 8
 #endif
 constexpr int BB_DEPTH = RMX_BB_DEPTH;
+#ifndef RMX_BB_PEND8
+#define RMX_BB_PEND8 0                        // a third level of waiting carries (weight 8)
+#endif
 #ifndef RMX_BB_WGS
 #define RMX_BB_WGS 2                          // workgroups per CU the register budget is set for
 #endif
@@ -77,11 +80,6 @@ __device__ __forceinline__ void bb_onehot(const uint32_t (&q)[4], uint32_t m, ui
   h[7] = bs::bop3<f_bb_hot<1, 1>>(q[0], q[1], z1);
 }
 
-// A pair of frames on its way through a lane (its bytes are in the LDS ring): the validity masks (both halves), the
-// clamp shifts (frame 1 in the low half, frame 2 in the high half)
-struct BbPair {
-  uint32_t m1, m2, shl, shr;
-};
 // what the scalar side knows of a frame: index, tile origin in frame coordinates
 struct BbFrame {
   uint32_t f;
@@ -90,7 +88,10 @@ struct BbFrame {
 
 struct BbCounters {
   uint32_t pl[8][8];                // pl[k][w]: bit k of the counts of word w's 32 (pixel, colour) slots
-  uint32_t pa[8], pA[8], pE[8];     // carries waiting for their partner: weight 2, 4, 8
+  uint32_t pa[8], pA[8];            // carries waiting for their partner: weight 2, 4
+#if RMX_BB_PEND8
+  uint32_t pE[8];                   // weight 8
+#endif
   uint32_t np;                      // pairs counted since the last flush (uniform; a multiple of eight between groups)
   bool wrote;                       // this tile's dots have been stored once (uniform)
 
@@ -127,6 +128,7 @@ struct BbCounters {
           const bs::Sum2 s = bs::full_add(pl[2][w], pA[w], c4[w]);
           pl[2][w] = s.s, c8[w] = s.c;
         }
+#if RMX_BB_PEND8
         if constexpr ((K & 4) == 0) {
 #pragma unroll
           for (int w = 0; w < 8; ++w) pE[w] = c8[w];
@@ -144,6 +146,20 @@ struct BbCounters {
             }
           }
         }
+#else
+        // (no third level of waiting carries: eight registers fewer, nine operations more per pair — what lets three
+        // waves share a SIMD)
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+          uint32_t cy = c8[w];  // weight 8: ripples through bits 3..7
+#pragma unroll
+          for (int k = 3; k < 8; ++k) {
+            const uint32_t nx = pl[k][w] & cy;
+            pl[k][w] ^= cy;
+            cy = nx;
+          }
+        }
+#endif
       }
     }
   }
@@ -161,7 +177,17 @@ struct BbCounters {
 };
 
 // counters -> canvas.  xb: BB_XSTRIDE * 64 bytes of the wave's LDS.
-__device__ __forceinline__ void bb_flush(const BlitParams& p, BbCounters& C, int X0, int Y0, uint32_t lane, uint8_t* xb) {
+// (NOT inlined, the counters passed by value: the flush gets its own register allocation, and what it spills stays
+// out of the frame loop — spill stores there would void the loop's hand-counted vmcnt, which takes the loads to
+// complete in order)
+struct BbPlanes {
+  uint32_t pl[8][8];
+};
+struct BbCanvas {
+  uint32_t* canvas;
+  uint32_t cw, ch;
+};
+__device__ __attribute__((noinline)) void bb_flush_planes(BbCanvas p, BbPlanes C, bool rd, int X0, int Y0, uint32_t lane, uint8_t* xb) {
   // 8 x 8 bit transposition per byte column, in place: afterwards byte b of pl[i][w] = count of slot 8 b + i of word w
 #pragma unroll
   for (int w = 0; w < 8; ++w) {
@@ -180,7 +206,6 @@ __device__ __forceinline__ void bb_flush(const BlitParams& p, BbCounters& C, int
   const uint32_t row_bytes = p.cw * 32u;
   const __amdgpu_buffer_rsrc_t crs = __builtin_amdgcn_make_buffer_rsrc(
       p.canvas + ((size_t)Y0 * p.cw + (size_t)X0) * 8, (short)0, (int)min((uint64_t)BB_ROWS * row_bytes, (uint64_t)0x7fffffffu), 0x00020000);
-  const bool rd = !p.fresh || C.wrote;
   auto wsync = [&]() __attribute__((always_inline)) {  // (LDS operations of a wave execute in order; this keeps the compiler from moving them)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -239,6 +264,15 @@ __device__ __forceinline__ void bb_flush(const BlitParams& p, BbCounters& C, int
   }
   // (the frame pipe counts its LDS-DMA loads by hand: nothing of this flush may still be in flight behind them)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void bb_flush(const BlitParams& p, BbCounters& C, int X0, int Y0, uint32_t lane, uint8_t* xb) {
+  BbPlanes P;
+#pragma unroll
+  for (int k = 0; k < 8; ++k)
+#pragma unroll
+    for (int w = 0; w < 8; ++w) P.pl[k][w] = C.pl[k][w];
+  bb_flush_planes(BbCanvas{p.canvas, p.cw, p.ch}, P, !p.fresh || C.wrote, X0, Y0, lane, xb);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   C.clear();
   C.wrote = true;
 }
@@ -249,9 +283,11 @@ constexpr uint32_t BB_NULL_LO = 0u, BB_NULL_HI = 0x80000000u;  // the frame that
 
 __global__ __launch_bounds__(256, RMX_BB_WGS) void fgm_blit_bs(BlitParams p) {
   constexpr int D = BB_DEPTH;
-  __shared__ __attribute__((aligned(16))) uint8_t ring[4][D][2][64 * 16];  // [wave][pair in flight][frame of the pair][lane's 16 bytes]
-  __shared__ __attribute__((aligned(16))) uint8_t xbuf[4][64 * BB_XSTRIDE];
-  __shared__ __attribute__((aligned(16))) uint2 queue[4][BB_QCAP];         // the chunk's frames that touch this wave's tile
+  constexpr uint32_t RING_BYTES = D * 2 * 64 * 16, XBUF_BYTES = 64 * BB_XSTRIDE;
+  // [wave][pair in flight][frame of the pair][lane's 16 bytes]; the flush turns the canvas rows round in the same
+  // memory (no pair is in flight then: the pipe holds its breath in the group before a flush)
+  __shared__ __attribute__((aligned(16))) uint8_t ring_mem[4][RING_BYTES > XBUF_BYTES ? RING_BYTES : XBUF_BYTES];
+  __shared__ __attribute__((aligned(16))) uint2 queue[4][BB_QCAP];  // the chunk's frames that touch this wave's tile
   const uint32_t lane = threadIdx.x & 63u;
   const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const uint32_t b = blit_tile_of_block();
@@ -266,29 +302,26 @@ __global__ __launch_bounds__(256, RMX_BB_WGS) void fgm_blit_bs(BlitParams p) {
   const int lrow = (int)(lane >> 2), lcol = (int)(lane & 3u) * 16;
   const uint32_t lane_off = (uint32_t)(lrow * W + lcol);
   uint2* q = queue[wv];
+  uint8_t* ring = ring_mem[wv];
 
   BbCounters C;
   C.clear();
 
-  // a frame's 16 bytes per lane -> LDS (LDS-DMA: no registers), its mask and clamp shift.  d: the queue's record
-  // (frame | window << 28, sx & 0xffff | fy << 16: the tile's origin in frame coordinates), uniform.
-  auto issue_one = [&](uint32_t d0, uint32_t d1, uint8_t* dst, uint32_t& m, uint32_t& l, uint32_t& r) __attribute__((always_inline)) {
-    const uint32_t f = d0 & 0x0fffffffu;
+  // A queue record (frame | window << 28, sx & 0xffff | fy << 16: the tile's origin in frame coordinates), uniform.
+  // The lane's 16 bytes are loaded from inside the frame's row (window clamped), `l` / `r` say how far the planes
+  // have to move to undo the clamp, `m` marks the lane's pixels that lie in the frame (both halves).
+  auto covers = [&](uint32_t d1) __attribute__((always_inline)) -> bool {  // (uniform) the frame covers the whole tile
     const int sx = (int)(short)(d1 & 0xffffu), fy = (int)d1 >> 16;
-    const uint8_t* fbase = p.frames + (uint64_t)f * fbytes;
+    return sx >= 0 && sx + BL_TW <= W && fy >= 0 && fy + BB_ROWS <= H;
+  };
+  auto load_one = [&](uint32_t d0, uint32_t d1, uint8_t* dst) __attribute__((always_inline)) {
+    const int sx = (int)(short)(d1 & 0xffffu), fy = (int)d1 >> 16;
+    const uint8_t* fbase = p.frames + (uint64_t)(d0 & 0x0fffffffu) * fbytes;
     uint32_t off;
-    if (sx >= 0 && sx + BL_TW <= W && fy >= 0 && fy + BB_ROWS <= H) {  // (uniform) the frame covers the tile
+    if (covers(d1)) {
       off = (uint32_t)(fy * W + sx) + lane_off;
-      m = 0xffffffffu, l = 0, r = 0;
     } else {
-      const int fyl = fy + lrow, xs = sx + lcol;
-      const int rowc = min(max(fyl, 0), H - 1), xsc = min(max(xs, 0), W - 16);
-      const int d = xs - xsc;
-      l = (uint32_t)max(-d, 0), r = (uint32_t)max(d, 0);
-      const int wd = (uint32_t)fyl < (uint32_t)H ? max(16 - (int)l - (int)r, 0) : 0;
-      const uint32_t m16 = ((1u << wd) - 1u) << (l & 15u);
-      m = m16 | m16 << 16;
-      l &= 15u, r &= 15u;
+      const int rowc = min(max(fy + lrow, 0), H - 1), xsc = min(max(sx + lcol, 0), W - 16);
       off = (uint32_t)(rowc * W + xsc);
     }
 #if defined(RMX_BB_NOLOAD)  /* ablation: everything but the loads */
@@ -297,45 +330,62 @@ __global__ __launch_bounds__(256, RMX_BB_WGS) void fgm_blit_bs(BlitParams p) {
     __builtin_amdgcn_global_load_lds((blit_glb_ptr)(fbase + off), (blit_lds_ptr)dst, 16, 0, 0);
 #endif
   };
-  BbPair P[D];
+  auto mask_one = [&](uint32_t d1, uint32_t& m, uint32_t& l, uint32_t& r) __attribute__((always_inline)) {
+    const int sx = (int)(short)(d1 & 0xffffu), fy = (int)d1 >> 16;
+    const int fyl = fy + lrow, xs = sx + lcol;
+    const int d = xs - min(max(xs, 0), W - 16);
+    l = (uint32_t)max(-d, 0), r = (uint32_t)max(d, 0);
+    const int wd = (uint32_t)fyl < (uint32_t)H ? max(16 - (int)l - (int)r, 0) : 0;
+    const uint32_t m16 = ((1u << wd) - 1u) << (l & 15u);
+    m = m16 | m16 << 16;
+    l &= 15u, r &= 15u;
+  };
+  auto record = [&](uint32_t pi, uint32_t& d0, uint32_t& d1, uint32_t& e0, uint32_t& e1) __attribute__((always_inline)) {
+    const uint4 d = *reinterpret_cast<const uint4*>(&q[2 * pi]);  // (the same address in every lane)
+    d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
+    e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w);
+  };
   uint32_t win = 0;  // barriers of this chunk executed so far (uniform)
   // pair `pi` of the chunk's queue goes out into ring slot S; the workgroup's waves meet once per window of 16 list
   // positions, each where its own queue crosses into the window (a wave without a frame there catches up later)
   auto issue = [&](auto stag, uint32_t pi) __attribute__((always_inline)) {
     constexpr int S = decltype(stag)::value;
-    const uint4 d = *reinterpret_cast<const uint4*>(&q[2 * pi]);  // (the same address in every lane)
-    const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.x), d1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.y);
-    const uint32_t e0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.z), e1 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d.w);
+    uint32_t d0, d1, e0, e1;
+    record(pi, d0, d1, e0, e1);
 #if !defined(RMX_BB_NOSYNC)
     while (win < (d0 >> 28)) {
       __builtin_amdgcn_s_barrier();
       ++win;
     }
 #endif
-    uint32_t l1, r1, l2, r2;
-    issue_one(d0, d1, &ring[wv][S][0][0], P[S].m1, l1, r1);
-    issue_one(e0, e1, &ring[wv][S][1][0], P[S].m2, l2, r2);
-    P[S].shl = l1 | l2 << 16;
-    P[S].shr = r1 | r2 << 16;
+    load_one(d0, d1, ring + (S * 2 + 0) * 1024);
+    load_one(e0, e1, ring + (S * 2 + 1) * 1024);
   };
-  auto consume = [&](auto ktag) __attribute__((always_inline)) {
+  auto consume = [&](auto ktag, uint32_t pi) __attribute__((always_inline)) {
     constexpr int K = decltype(ktag)::value, s = K % D;
-    const bb_u32x4 ra = *reinterpret_cast<const bb_u32x4*>(&ring[wv][s][0][lane * 16]);
-    const bb_u32x4 rb = *reinterpret_cast<const bb_u32x4*>(&ring[wv][s][1][lane * 16]);
+    const bb_u32x4 ra = *reinterpret_cast<const bb_u32x4*>(ring + (s * 2 + 0) * 1024 + lane * 16);
+    const bb_u32x4 rb = *reinterpret_cast<const bb_u32x4*>(ring + (s * 2 + 1) * 1024 + lane * 16);
+    uint32_t d0, d1, e0, e1;
+    record(pi, d0, d1, e0, e1);
     const uint32_t a[4] = {ra[0], ra[1], ra[2], ra[3]}, bq[4] = {rb[0], rb[1], rb[2], rb[3]};
     uint32_t n[4];
     bs::planes_from_bytes(a, bq, n);
-    if (__builtin_amdgcn_ballot_w64((P[s].shl | P[s].shr) != 0) != 0) {  // (uniform) a frame's edge crosses the tile
+    uint32_t m1 = 0xffffffffu, m2 = 0xffffffffu;
+    if (!covers(d1) || !covers(e1)) {  // (uniform) a frame's edge crosses the tile
+      uint32_t l1, r1, l2, r2;
+      mask_one(d1, m1, l1, r1);
+      mask_one(e1, m2, l2, r2);
+      const uint32_t shl = l1 | l2 << 16, shr = r1 | r2 << 16;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) n[k] = bb_pk_shr(bb_pk_shl(n[k], P[s].shl), P[s].shr);
+      for (int k = 0; k < 4; ++k) n[k] = bb_pk_shr(bb_pk_shl(n[k], shl), shr);
     }
     uint32_t qq[4], h1[8], h2[8];
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = __builtin_amdgcn_perm(n[k], n[k], 0x01000100u);
-    bb_onehot(qq, P[s].m1, h1);
+    bb_onehot(qq, m1, h1);
 #pragma unroll
     for (int k = 0; k < 4; ++k) qq[k] = __builtin_amdgcn_perm(n[k], n[k], 0x03020302u);
-    bb_onehot(qq, P[s].m2, h2);
+    bb_onehot(qq, m2, h2);
     C.template add_pair<K>(h1, h2);
   };
   static_assert(8 % D == 0, "a group of eight pairs walks the ring a whole number of times");
@@ -364,37 +414,49 @@ __global__ __launch_bounds__(256, RMX_BB_WGS) void fgm_blit_bs(BlitParams p) {
     wsync();
     // ---- pass 2: groups of eight pairs in straight-line code (pair k of a group: ring slot k % D, tree position k);
     // D pairs in the pipe.  LDS-DMA loads land in order, two per pair: all but the 2 (D - 1) youngest have landed
-    // after vmcnt(that many); the chunk's last D - 1 pairs wait for everything.
+    // after vmcnt(that many); where fewer pairs follow (the chunk's end, the group before a flush) wait for everything.
     const uint32_t npairs = (nq + 15u) / 16u * 8u;
     win = 0;
-    if (npairs) {
-      issue(std::integral_constant<int, 0>{}, 0u);
-      if constexpr (D > 1) issue(std::integral_constant<int, 1 % D>{}, 1u);
-      if constexpr (D > 2) issue(std::integral_constant<int, 2 % D>{}, 2u);
-      if constexpr (D > 2) issue(std::integral_constant<int, 3 % D>{}, 3u);
-    }
-    auto step = [&](auto ktag, uint32_t pi) __attribute__((always_inline)) {
-      constexpr int K = decltype(ktag)::value;
-      if (pi + D <= npairs) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#if defined(RMX_BB_NOCOMPUTE)  /* ablation: the loads and the walk only */
-      asm volatile("" ::"v"(P[K % D].m1), "v"(P[K % D].m2), "v"(P[K % D].shl), "v"(P[K % D].shr));
-#else
-      consume(ktag);
-#endif
-      if (pi + D < npairs) issue(std::integral_constant<int, K % D>{}, pi + D);
+    auto prime = [&](uint32_t base) __attribute__((always_inline)) {
+      if (base + 0 < npairs) issue(std::integral_constant<int, 0>{}, base + 0);
+      if (D > 1 && base + 1 < npairs) issue(std::integral_constant<int, 1 % D>{}, base + 1);
+      if (D > 2 && base + 2 < npairs) issue(std::integral_constant<int, 2 % D>{}, base + 2);
+      if (D > 2 && base + 3 < npairs) issue(std::integral_constant<int, 3 % D>{}, base + 3);
+      if (D > 4 && base + 4 < npairs) issue(std::integral_constant<int, 4 % D>{}, base + 4);
+      if (D > 4 && base + 5 < npairs) issue(std::integral_constant<int, 5 % D>{}, base + 5);
+      if (D > 4 && base + 6 < npairs) issue(std::integral_constant<int, 6 % D>{}, base + 6);
+      if (D > 4 && base + 7 < npairs) issue(std::integral_constant<int, 7 % D>{}, base + 7);
     };
-    for (uint32_t g = 0; g < npairs; g += 8) {
-      step(std::integral_constant<int, 0>{}, g);
-      step(std::integral_constant<int, 1>{}, g + 1);
-      step(std::integral_constant<int, 2>{}, g + 2);
-      step(std::integral_constant<int, 3>{}, g + 3);
-      step(std::integral_constant<int, 4>{}, g + 4);
-      step(std::integral_constant<int, 5>{}, g + 5);
-      step(std::integral_constant<int, 6>{}, g + 6);
-      step(std::integral_constant<int, 7>{}, g + 7);
-      C.np += 8;
-      if (C.np == BB_FLUSH_PAIRS) bb_flush(p, C, X0, Y0, lane, xbuf[wv]);
+    prime(0);
+    for (uint32_t g = 0; g < npairs;) {
+      // the groups up to the next flush (or the chunk's end): no pair beyond `stop` goes out before it.  (The flush is
+      // a call: kept out of the innermost loop, so is what the compiler saves around it.)
+      const uint32_t stop = min(npairs, g + (BB_FLUSH_PAIRS - C.np));
+#pragma unroll 1
+      for (; g < stop; g += 8) {
+        auto step = [&](auto ktag, uint32_t pi) __attribute__((always_inline)) {
+          constexpr int K = decltype(ktag)::value;
+          if (pi + D <= stop) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (D - 1)) : "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#if !defined(RMX_BB_NOCOMPUTE)  /* ablation: the loads and the walk only */
+          consume(ktag, pi);
+#endif
+          if (pi + D < stop) issue(std::integral_constant<int, K % D>{}, pi + D);
+        };
+        step(std::integral_constant<int, 0>{}, g);
+        step(std::integral_constant<int, 1>{}, g + 1);
+        step(std::integral_constant<int, 2>{}, g + 2);
+        step(std::integral_constant<int, 3>{}, g + 3);
+        step(std::integral_constant<int, 4>{}, g + 4);
+        step(std::integral_constant<int, 5>{}, g + 5);
+        step(std::integral_constant<int, 6>{}, g + 6);
+        step(std::integral_constant<int, 7>{}, g + 7);
+        C.np += 8;
+      }
+      if (C.np == BB_FLUSH_PAIRS) {
+        bb_flush(p, C, X0, Y0, lane, ring);
+        prime(g);
+      }
     }
 #if !defined(RMX_BB_NOSYNC)
     while (win < BB_CHUNK / 16) {
@@ -404,7 +466,7 @@ __global__ __launch_bounds__(256, RMX_BB_WGS) void fgm_blit_bs(BlitParams p) {
 #endif
     wsync();  // (the queue is rewritten by the next chunk)
   }
-  if (C.np != 0 || (p.fresh && !C.wrote)) bb_flush(p, C, X0, Y0, lane, xbuf[wv]);
+  if (C.np != 0 || (p.fresh && !C.wrote)) bb_flush(p, C, X0, Y0, lane, ring);
 }
 
 }  // namespace rmx

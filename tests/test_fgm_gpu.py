@@ -9,6 +9,16 @@ from remap_amd.synth import scroller_v1
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["lds", "lds-unsorted", "bitplanes"], autouse=True)
+def blit_kernel(request, monkeypatch):
+    """Every test of this module runs with fgm.hip's kernel (the default; its group lists sorted by frame residue, and
+    as the binning atomics leave them) and with the bit-plane kernel of fgm_bs.hip (RMX_BLIT_BS=1: frames without a
+    mask, at least 64 pixels wide — the others take fgm.hip's kernels either way).  The switches are read per call."""
+    monkeypatch.setenv("RMX_BLIT_BS", "1" if request.param == "bitplanes" else "0")
+    monkeypatch.setenv("RMX_BLIT_STRIDE", "0" if request.param == "lds-unsorted" else "32")
+    return request.param
+
+
 def test_extent_matches_oracle_and_is_order_independent():
     lib = L.load()
     rng = np.random.default_rng(2)
