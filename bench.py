@@ -192,7 +192,7 @@ def headline_profiles(kernel_name):
 def other_workloads(torch, args, only=None):
     """The BASELINE.json workloads beside the headline's, one GPU, timed in this run (`only`: just that one — what
     tools/profile_round_r04.sh runs under rocprofv3 for the per-workload kernel statistics)."""
-    from remap_amd.pipeline import Aligner
+    from remap_amd.pipeline import Aligner, AlignerPipe
     from remap_amd.splice import splice
     from remap_amd.synth import rooms_v1, scroller_v1, upscale2
 
@@ -221,6 +221,20 @@ def other_workloads(torch, args, only=None):
         res["config4_doubled"] = dict(time_stream(torch, d, 640, 480, 4096, steps, args.lanes),
                                       workload=f"{n} frames 640x480 = scroller-v1 pixel-doubled (configs[3] 'upscaled capture'; a doubled "
                                                "patch rarely yields keypoints — ~4 per frame — so about one frame in ten opens a new fragment)")
+        # with the canvas blit: blocks in flight as in the headline's tier B (the host-side stage of block t — positions
+        # to the host, ~1 000 canvas boxes — and its blit beside the alignment of block t + 1)
+        pipe4 = AlignerPipe(640, 480, kmax=4096, lanes=args.lanes)
+        for _ in range(2):
+            pipe4.submit(d, blit=True)
+        pipe4.drain()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            pipe4.submit(d, blit=True)
+        pipe4.drain()
+        torch.cuda.synchronize()
+        res["config4_doubled"]["frames_per_s_with_blit"] = n * 6 / (time.perf_counter() - t0)
+        pipe4.close()
         al = Aligner(640, 480, kmax=4096)
         al.align(d, blit=True)
         torch.cuda.synchronize()
@@ -228,7 +242,7 @@ def other_workloads(torch, args, only=None):
         for _ in range(3):
             al.align(d, blit=True)
         torch.cuda.synchronize()
-        res["config4_doubled"]["frames_per_s_with_blit"] = n * 3 / (time.perf_counter() - t0)
+        res["config4_doubled"]["frames_per_s_with_blit_one_block_in_flight"] = n * 3 / (time.perf_counter() - t0)
         al.close()
         del d, small
     torch.cuda.empty_cache()

@@ -18,6 +18,8 @@ positions (12 B/frame) are gathered only to size fragment canvases.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import lib as L
