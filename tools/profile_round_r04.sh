@@ -43,5 +43,9 @@ PN="10000 200 640 480" PD="" pmc config4_native_pmc_kpe_pc "kpe_pc<4" RMX_PC_DEN
 bash tools/pmc_blit.sh ${TAG}_blit > $OUT/pmc_blit.log 2>&1 || tail -5 $OUT/pmc_blit.log
 cp gpurun_out/pmc_${TAG}_blit/pmc_fgm_blit.json $OUT/${TAG}_blit_pmc_fgm_blit.json || true
 rm -rf gpurun_out/pmc_${TAG}_blit
+# the bit-plane blit kernel (fgm_bs.hip, behind RMX_BLIT_BS=1), for the record
+( export RMX_BLIT_BS=1; bash tools/pmc_blit.sh ${TAG}_blit_bs ) > $OUT/pmc_blit_bs.log 2>&1 || tail -5 $OUT/pmc_blit_bs.log
+cp gpurun_out/pmc_${TAG}_blit_bs/pmc_fgm_blit.json $OUT/${TAG}_blit_pmc_fgm_blit_bs.json || true
+rm -rf gpurun_out/pmc_${TAG}_blit_bs
 ls -la $OUT
 head -c 1200 $OUT/${TAG}_bench.json
