@@ -235,6 +235,9 @@ constexpr int BL_ROWS = RMX_BL_ROWS, BL_DEPTH = RMX_BL_DEPTH, BL_ROWS_NARROW = 4
 #ifndef RMX_BLIT_SYNC
 #define RMX_BLIT_SYNC 16  // list positions between two barriers of a workgroup's waves (a divisor of 64; 0: none): 2.17 -> 1.43 GB fetched per 10 000 frames, same time (4: also 1.43 GB, +10 % time)
 #endif
+#ifndef RMX_BLIT_ST_AUX
+#define RMX_BLIT_ST_AUX 0  // cache policy of the canvas stores (2: non-temporal)
+#endif
 #ifndef RMX_BLIT_XFOLD
 #define RMX_BLIT_XFOLD 1  // canvas rows cross the memory interface in memory order (BlitCounters::fold_canvas_x)
 #endif
@@ -441,8 +444,8 @@ struct BlitCounters {
         // (as in kpe_bs / kpe_pc: nothing may be scheduled between a 16-byte store with a scalar offset and the
         // wait states behind it — tools/check_store_hazard.py)
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_raw_buffer_store_b128(m0, crs, vo0, so, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(m1, crs, vo1, so, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(m0, crs, vo0, so, RMX_BLIT_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(m1, crs, vo1, so, RMX_BLIT_ST_AUX);
         asm volatile("s_nop 1");
         __builtin_amdgcn_sched_barrier(0);
       }
