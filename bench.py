@@ -311,6 +311,8 @@ def main():
                                                       "multi-rank flow on one GPU")
     args = ap.parse_args()
 
+    # (the pool's hosts share device memory between processes through dmabuf handles only: RCCL needs this before HIP starts)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     import torch
 
     from remap_amd import lib as L
