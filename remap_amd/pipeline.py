@@ -18,8 +18,6 @@ positions (12 B/frame) are gathered only to size fragment canvases.
 """
 from __future__ import annotations
 
-import os
-
 import numpy as np
 
 from . import lib as L
