@@ -1037,13 +1037,23 @@ template <typename F>
 __device__ __forceinline__ void kpm_for_tier(const uint32_t* tier, uint32_t want, uint32_t nslots, uint32_t* status, uint32_t bit, F&& frame) {
   // workgroup b owns frames b, b + G, b + 2G, ... (neighbouring frames cost alike: striding
   // spreads them over the workgroups)
+  // (the FIRST wave looks at the tier words, 64 frames a trip; the others only meet it at the barrier: a workgroup
+  // that finds nothing waiting — nearly all of them on a sparse stream — costs its other waves a dozen instructions)
+  __shared__ uint32_t s_any;
   const uint32_t G = gridDim.x, b = blockIdx.x;
   const uint32_t K = b < nslots ? (nslots - b + G - 1) / G : 0;
-  for (uint32_t base = 0; base < K; base += blockDim.x) {
-    const uint32_t k = base + threadIdx.x;
-    const bool mine = tier == nullptr || (k < K && tier[b + k * G] == want);
-    if (!__syncthreads_or(mine)) continue;
-    const uint32_t end = min(K, base + blockDim.x);
+  for (uint32_t base = 0; base < K; base += 64) {
+    if (threadIdx.x < 64) {
+      const uint32_t k = base + threadIdx.x;
+      const bool mine = tier == nullptr || (k < K && tier[b + k * G] == want);
+      const bool any = __builtin_amdgcn_ballot_w64(mine) != 0;
+      if (threadIdx.x == 0) s_any = any ? 1u : 0u;
+    }
+    __syncthreads();
+    const bool any = s_any != 0;
+    __syncthreads();  // (s_any is rewritten by the next trip)
+    if (!any) continue;
+    const uint32_t end = min(K, base + 64);
     for (uint32_t kk = base; kk < end; ++kk) {
       const uint32_t fslot = b + kk * G;
       if (tier && tier[fslot] != want) continue;  // uniform
