@@ -14,16 +14,26 @@
 //   edge frames only: the planes shifted by the clamp (v_pk_lsh*_b16, per frame), the validity mask
 //   planes duplicated into both halves (4 v_perm), one-hot words: (q3 ^ 0x0000ffff) & mask, x q2, x (q0, q1): 11
 //   counters: a carry-save tree — full adder (ones, h1, h2) per pair of frames, (twos, a, b) per two pairs,
-//   (fours, ..) per four, (eights, ..) per eight, then a ripple into bits 4..7 every 16 frames: ~2.4 operations
-//   per word and frame
+//   (fours, ..) per four, then a ripple into bits 3..7 (RMX_BB_PEND8=1: one more level of waiting carries, a ripple
+//   into bits 4..7 every 16 frames): ~2.5-3 operations per word and frame
 //
-// ~70 lane operations for 16 pixels against ~220 in fgm_blit.  A wave owns 64 canvas columns x 16 rows (lane:
-// row lane / 4, columns 16 (lane % 4)), a workgroup four such tiles side by side, walking the same binned frame
-// list with a barrier every 16 list positions exactly as fgm_blit does (neighbours ask for a line of a frame row
-// within a few frames of each other).  After 240 frames at most, and at the end, the 8 x 8 planes are transposed in
-// place (three delta-swap stages: byte b of word i = the count of slot 8 b + i), widened to the canvas's uint16
-// bins with one v_perm per dword and added to / written over the canvas in full 128-byte lines (four dots of a
-// lane per phase, turned round through LDS so that eight lanes write one line).
+// ~75 lane operations for 16 pixels against ~220 in fgm_blit.  A wave owns 64 canvas columns x 16 rows (lane:
+// row lane / 4, columns 16 (lane % 4)), a workgroup four such tiles side by side on the same binned frame list.
+// The list is taken 256 positions at a time: a first pass tests the records against the tile (a lane per record) and
+// queues the matching frames in the wave's LDS; the second pass runs GROUPS OF EIGHT PAIRS in straight-line code —
+// ring slot and tree position of a pair are compile-time, so no counter update sits in a conditional block (with
+// run-time positions the register allocator shuffled the 88 counter registers at every join) — with D pairs in
+// flight through an LDS-DMA ring; the queue is padded with frames that count nothing.  The workgroup's waves meet
+// at a barrier once per 16 list positions, each where its own queue crosses into the window, as in fgm_blit
+// (neighbours ask for a line of a frame row within a few frames of each other).  After 240 frames at most, and at
+// the end, the 8 x 8 planes are transposed in place (three delta-swap stages: byte b of word i = the count of slot
+// 8 b + i), widened to the canvas's uint16 bins with one v_perm per dword and added to / written over the canvas in
+// 64-byte pieces (two dots of a lane per phase, turned round through LDS — the ring's memory, idle then — so that
+// four lanes write one piece).  The flush is a CALL with the planes passed by value: its register allocation is its
+// own, and what it spills stays out of the frame loop, where a spill store would void the hand-counted vmcnt.
+//
+// Status: bit-exact, 0.6 of fgm_blit's instructions, and slower — 150-250 registers leave two waves
+// per SIMD, too few to hide the dependent-issue latency of a pair's ~180 instructions.  Behind RMX_BLIT_BS=1.
 //
 // Frames with a mask and frames narrower than 64 pixels stay with fgm.hip's kernels.
 #pragma once
