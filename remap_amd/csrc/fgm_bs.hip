@@ -90,12 +90,6 @@ __device__ __forceinline__ void bb_onehot(const uint32_t (&q)[4], uint32_t m, ui
   h[7] = bs::bop3<f_bb_hot<1, 1>>(q[0], q[1], z1);
 }
 
-// what the scalar side knows of a frame: index, tile origin in frame coordinates
-struct BbFrame {
-  uint32_t f;
-  int sx, fy;
-};
-
 struct BbCounters {
   uint32_t pl[8][8];                // pl[k][w]: bit k of the counts of word w's 32 (pixel, colour) slots
   uint32_t pa[8], pA[8];            // carries waiting for their partner: weight 2, 4
