@@ -109,14 +109,15 @@ def test_blocks_in_flight_equal_blocks_one_by_one(gpu):
         o = al.align(b)
         want.append(({k: o[k].clone() for k in ("dxdy", "matched", "pos", "frag", "kcount", "median")}, o["nfrag"]))
     al.close()
-    for lanes in (2, 3, 1):
-        pipe = AlignerPipe(320, 240, kmax=2048, lanes=lanes)
+    for lanes, depth in ((2, 1), (3, 1), (1, 1), (2, 2)):  # (depth: buffer sets per stream, taken in turn)
+        pipe = AlignerPipe(320, 240, kmax=2048, lanes=lanes, depth=depth)
+        slots = lanes * depth
         for rep in range(2):
-            outs = [pipe.align(b) for b in blocks[:lanes]]  # (a lane's buffers are reused by its next block)
-            assert pipe.finish() == want[lanes - 1][1]
+            outs = [pipe.align(b) for b in blocks[:slots]]  # (a slot's buffers are reused by its next block)
+            assert pipe.finish() == want[slots - 1][1]
             for o, (w, _) in zip(outs, want):
                 for k, v in w.items():
-                    assert torch.equal(o[k], v), (lanes, k)
+                    assert torch.equal(o[k], v), (lanes, depth, k)
         # more blocks than lanes: each block is settled and read before its lane is used again
         for i, b in enumerate(blocks):
             o = pipe.align(b)
